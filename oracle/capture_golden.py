@@ -1,0 +1,326 @@
+#!/usr/bin/env python3 -B
+"""Generate tests/golden/*.npz by running the REFERENCE itself on CPU.
+
+TEST INFRASTRUCTURE ONLY.  Runs only in the build container (it imports
+/root/reference, which never travels to the GPU box); the resulting .npz files
+are committed.  Usage:
+
+    python3 -B oracle/capture_golden.py [--out tests/golden]
+
+Shims (none edits a reference file):
+  * `torch_geometric` is not installed.  Placeholder modules are registered so
+    that the class *bodies* of models/direction_diffusion.py, models/base_models.py
+    and utils/data_utils.py import; the placeholder GCNConv is never called (all
+    captures use the mlp denoiser / graphset=True path).  `gcndec` therefore stays
+    PARITY UNPINNED.
+  * The diffusion class hard-codes `.cuda()` (direction_diffusion.py:108-118,
+    203-204); on this CPU-only container Tensor.cuda is made the identity.
+  * torch.randint / torch.randn / torch.randn_like are swapped for injected
+    tensors while `forward` / `p_sample_loop` run, so the draws are part of the
+    fixture.
+"""
+import argparse
+import contextlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+
+from oracle import golden_inputs as gi  # noqa: E402
+
+
+def install_shims():
+    class _GCNConvPlaceholder(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+        def forward(self, *a, **k):
+            raise RuntimeError("torch_geometric is absent: GCNConv is a placeholder")
+
+    names = ["torch_geometric", "torch_geometric.nn", "torch_geometric.datasets",
+             "torch_geometric.transforms", "torch_geometric.utils",
+             "torch_geometric.utils.convert", "torch_geometric.data"]
+    mods = {n: types.ModuleType(n) for n in names}
+    mods["torch_geometric.nn"].GCNConv = _GCNConvPlaceholder
+    mods["torch_geometric.utils.convert"].to_networkx = None
+    for a in ("Data", "InMemoryDataset", "download_url", "extract_tar"):
+        setattr(mods["torch_geometric.data"], a, object)
+    for n, m in mods.items():
+        sys.modules[n] = m
+        if "." in n:
+            parent, child = n.rsplit(".", 1)
+            setattr(mods[parent], child, m)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, REF)
+    os.chdir(REF)
+
+
+@contextlib.contextmanager
+def injected(**repl):
+    old = {k: getattr(torch, k) for k in repl}
+    try:
+        for k, v in repl.items():
+            setattr(torch, k, v)
+        yield
+    finally:
+        for k, v in old.items():
+            setattr(torch, k, v)
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.array(a, copy=True))     # never alias the input arrays
+    return t.to(dtype) if dtype is not None else t
+
+
+def N(t):
+    return t.detach().cpu().numpy().copy()
+
+
+# ------------------------------------------------------------------------------
+def capture_manifolds(out_dir):
+    import manifolds
+    for mname in ("PoincareBall", "Hyperboloid"):
+        man = getattr(manifolds, mname)()
+        store = {}
+        for dt_name, npdt in (("f32", np.float32), ("f64", np.float64)):
+            for c in gi.MANIFOLD_CS:
+                for d in gi.MANIFOLD_DIMS:
+                    for s in gi.MANIFOLD_SCALES:
+                        u_, v_, w_ = gi.manifold_case(d, s, npdt)
+                        u, v, w = T(u_), T(v_), T(w_)
+                        key = f"{dt_name}/c{c}/d{d}/s{s:g}/"
+                        r = {"u": u, "v": v, "w": w}
+                        r["proj"] = man.proj(u, c)
+                        r["expmap0"] = man.expmap0(u, c)
+                        p = man.proj(man.expmap0(man.proj_tan0(u, c), c), c)
+                        q = man.proj(man.expmap0(man.proj_tan0(v, c), c), c)
+                        r["p"], r["q"] = p, q
+                        r["logmap0"] = man.logmap0(p, c)
+                        r["mobius_matvec"] = man.mobius_matvec(w, p, c)
+                        r["sqdist"] = man.sqdist(p, q, c)
+                        r["mobius_add"] = man.mobius_add(p, q, c)
+                        r["proj_tan0"] = man.proj_tan0(u, c)
+                        if mname == "PoincareBall":
+                            r["expmap"] = man.expmap(v, p, c)
+                            r["logmap"] = man.logmap(p, q, c)
+                        # tensor-valued curvature (hyp_layers.py:35) must agree with float c
+                        ct = torch.tensor([c])
+                        r["logmap0_ctensor"] = man.logmap0(p, ct)
+                        for k, val in r.items():
+                            store[key + k] = N(val)
+        np.savez_compressed(os.path.join(out_dir, f"manifold_{mname}.npz"), **store)
+        print(mname, len(store), "arrays")
+
+
+# ------------------------------------------------------------------------------
+def lp_args(manifold, c, n, feat, dim, bias):
+    return types.SimpleNamespace(
+        manifold=manifold, c=c, cuda=-1, device="cpu", feat_dim=feat, n_nodes=n,
+        model="HGCN", r=2.0, t=1.0, nb_false_edges=1, nb_edges=1, dim=dim, hid1=8,
+        hid2=4, num_layers=2, act="relu", dropout=0.0, bias=bias, use_att=0,
+        local_agg=0, task="lp", n_heads=4, alpha=0.6, pretrained_embeddings=None,
+        use_feats=0)
+
+
+def capture_layers(out_dir):
+    import scipy.sparse as sp
+    from utils import data_utils
+    from models.base_models import LPModel
+    store = {}
+    cases = [("ba", 100, 32), ("ego", 17, 16), ("community", 12, 14), ("citation", 300, 32)]
+    for kind, n, dim in cases:
+        adj = gi.synthetic_graph(kind, n)
+        # reference split + preprocessing (utils/data_utils.py:59-79,103-133)
+        adj_train, tr, trf, va, vaf, te, tef = data_utils.mask_edges(adj, 0.05, 0.1, 1432)
+        adj_t, feats = data_utils.process(adj_train, sp.eye(n).tocsr(), 1, 1)
+        g = f"{kind}{n}/"
+        store[g + "adj_in_indptr"] = adj.indptr.astype(np.int64)
+        store[g + "adj_in_indices"] = adj.indices.astype(np.int64)
+        store[g + "adj_train_indptr"] = adj_train.tocsr().indptr.astype(np.int64)
+        store[g + "adj_train_indices"] = adj_train.tocsr().indices.astype(np.int64)
+        store[g + "coo_indices"] = N(adj_t._indices())
+        store[g + "coo_values"] = N(adj_t._values())
+        store[g + "train_edges"] = N(tr)
+        store[g + "test_edges"] = N(te)
+        store[g + "features"] = N(feats)
+        for mname, c in (("PoincareBall", 0.6), ("Hyperboloid", 1.0)):
+            for bias in (0, 1):
+                if bias and kind not in ("ego",):
+                    continue
+                torch.manual_seed(1432)
+                args = lp_args(mname, c, n, n, dim, bias)
+                model = LPModel(args).eval()
+                if bias:
+                    with torch.no_grad():
+                        for lyr in model.encoder.layers:
+                            lyr.linear.bias.normal_(0, 0.1)
+                k = g + f"{mname}/bias{bias}/"
+                layers = list(model.encoder.layers)
+                for i, lyr in enumerate(layers):
+                    store[k + f"W{i}"] = N(lyr.linear.weight)
+                    store[k + f"b{i}"] = N(lyr.linear.bias)
+                with torch.no_grad():
+                    x = feats
+                    if mname == "Hyperboloid":
+                        x = torch.cat([torch.zeros_like(x)[:, 0:1], x], dim=1)
+                    man = model.manifold
+                    cs = model.encoder.curvatures
+                    h = man.proj(man.expmap0(man.proj_tan0(x, cs[0]), c=cs[0]), c=cs[0])
+                    store[k + "lift"] = N(h)
+                    for i, lyr in enumerate(layers):
+                        h1 = lyr.linear.forward(h)
+                        h2 = lyr.agg.forward(h1, adj_t)
+                        h3 = lyr.hyp_act.forward(h2)
+                        store[k + f"L{i}/linear"] = N(h1)
+                        store[k + f"L{i}/agg"] = N(h2)
+                        store[k + f"L{i}/act"] = N(h3)
+                        h = h3
+                    enc, _, _, _ = model.encode(feats, adj_t)
+                    store[k + "encode"] = N(enc)
+                    assert torch.equal(enc, h)
+                    store[k + "decode_train"] = N(model.decode(enc, tr))
+    np.savez_compressed(os.path.join(out_dir, "layers.npz"), **store)
+    print("layers", len(store), "arrays")
+
+
+# ------------------------------------------------------------------------------
+def load_mlp(diff, dim):
+    params = gi.mlp_params(dim)
+    with torch.no_grad():
+        for i, (w, b) in enumerate(params, 1):
+            fc = getattr(diff.mlp, f"fc{i}")
+            fc.weight.copy_(T(w)); fc.bias.copy_(T(b))
+
+
+def retable(diff, mod, Tn):
+    """Re-derive the instance tables for another horizon with the reference's own
+    module-level get_alphas (direction_diffusion.py:71-81), same expressions as
+    its __init__ (:96-107)."""
+    diff.num_timesteps = Tn
+    diff.alphas, betas = mod.get_alphas(Tn)
+    diff.alphas_cumprod = torch.cumprod(diff.alphas, dim=0)
+    diff.minus_alphas_cumprod = torch.sqrt(1. - diff.alphas_cumprod)
+    diff.sqrt_alphas_cumprod = torch.sqrt(diff.alphas_cumprod)
+    diff.sqrt_recip_alphas_cumprod = torch.sqrt(1. / diff.alphas_cumprod)
+    diff.sqrt_recipm1_alphas_cumprod = torch.sqrt(1. / diff.alphas_cumprod - 1)
+
+
+def capture_diffusion(out_dir):
+    import models.direction_diffusion as dd
+    store = {}
+    n, dim, k = 24, 16, 3
+    args = types.SimpleNamespace(r=2.0, t=1.0)
+    torch.manual_seed(1432)
+    diff = dd.diffusion(args, dim).eval()
+    load_mlp(diff, dim)
+    for name in ("alphas", "alphas_cumprod", "sqrt_alphas_cumprod", "minus_alphas_cumprod",
+                 "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod"):
+        store[f"T200/{name}"] = N(getattr(diff, name))
+    a2, m2 = diff.get_alphas2(200)
+    store["T200/get_alphas2_sqrt"] = N(a2); store["T200/get_alphas2_minus"] = N(m2)
+    tt = torch.arange(0, 200, dtype=torch.long)
+    store["T200/getpri"] = N(diff.getpri(tt))
+
+    case = gi.diffusion_case(n, dim, k)
+    rs = case["rs"]
+    labels = case["labels"]
+    u0 = T(case["u0"])
+    direction = [diff.manifold.logmap0(u, c=1.0) for u in u0]
+    store["c/x"], store["c/u0"], store["c/labels"] = case["x"], case["u0"], labels
+    store["c/noise"], store["c/img"] = case["noise"], case["img"]
+    store["c/direction"] = N(torch.stack(direction))
+    t = T(rs.randint(0, 200, size=n).astype(np.int64))
+    store["c/t"] = N(t)
+
+    with torch.no_grad():
+        for xdt, ndt, tag in ((torch.float64, torch.float64, "f64f64"),
+                              (torch.float32, torch.float64, "f32f64"),
+                              (torch.float32, torch.float32, "f32f32")):
+            x = T(case["x"], xdt)
+            for restrict in (False, True):
+                nz = T(case["noise"], ndt)
+                out = diff.q_sample(x, t, direction, nz, labels, u0, restrict=restrict)
+                store[f"q_sample/{tag}/restrict{int(restrict)}/out"] = N(out)
+                store[f"q_sample/{tag}/restrict{int(restrict)}/noise_after"] = N(nz)
+            x0 = T(case["noise"], torch.float32).clamp(-1, 1)
+            store[f"predict_noise/{tag}"] = N(diff.predict_noise_from_start(x, t, x0))
+
+        # denoiser alone, both time encodings (:276-278 integer t, :355 t/T)
+        x = T(case["x"], torch.float64)
+        store["mlp/int_t"] = N(diff.mlp(x, t))
+        store["mlp/frac_t"] = N(diff.mlp(x, t / 200))
+
+        # single p_sample steps from fp32 and fp64 states
+        for tag, xdt in (("f32", torch.float32), ("f64", torch.float64)):
+            for step in (150, 1, 0):
+                xin = T(case["img"], xdt)
+                pred, x0 = diff.p_sample(xin, None, 1, direction, labels, u0, step, None, True)
+                store[f"p_sample/{tag}/t{step}/pred"] = N(pred)
+                store[f"p_sample/{tag}/t{step}/x_start"] = N(x0)
+        # three consecutive steps
+        img = T(case["img"], torch.float32)
+        for step in (199, 198, 197):
+            img, x0 = diff.p_sample(img, None, 1, direction, labels, u0, step, None, True)
+            store[f"p_sample/chain/t{step}"] = N(img)
+
+        # training forward with injected draws (x is mutated in place by the reference)
+        for tag, xdt in (("f32", torch.float32), ("f64", torch.float64)):
+            xin = T(case["x"], xdt).clone()
+            nz = T(case["noise"], torch.float64)
+            with injected(randint=lambda *a, **k: t.clone(), randn_like=lambda *a, **k: nz.clone()):
+                loss = diff(xin, 1, labels, u0, restrict=True, graphset=True)
+            store[f"forward/{tag}/loss"] = N(loss)
+            store[f"forward/{tag}/x_after"] = N(xin)
+
+        # full sampling loop, injected initial Gaussian
+        for tag, xdt in (("f32", torch.float32),):
+            xin = T(case["x"], xdt).clone()
+            img0 = T(case["img"], torch.float32)
+            with injected(randn=lambda *a, **k: img0.clone()):
+                ret = diff.p_sample_loop(xin, 1, labels, u0, graphset=True)
+            store[f"p_sample_loop/{tag}/ret"] = N(ret)
+            store[f"p_sample_loop/{tag}/x_after"] = N(xin)
+
+        # T=1000 horizon (config 2): tables via the reference's own get_alphas
+        retable(diff, dd, 1000)
+        for name in ("alphas_cumprod", "sqrt_alphas_cumprod", "minus_alphas_cumprod",
+                     "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod"):
+            store[f"T1000/{name}"] = N(getattr(diff, name))
+        store["T1000/getpri"] = N(diff.getpri(torch.arange(0, 1000, dtype=torch.long)))
+        for step in (999, 500, 0):
+            xin = T(case["img"], torch.float32)
+            pred, x0 = diff.p_sample(xin, None, 1, direction, labels, u0, step, None, True)
+            store[f"T1000/p_sample/t{step}/pred"] = N(pred)
+            store[f"T1000/p_sample/t{step}/x_start"] = N(x0)
+    np.savez_compressed(os.path.join(out_dir, "diffusion.npz"), **store)
+    print("diffusion", len(store), "arrays")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    out = os.path.abspath(a.out)
+    os.makedirs(out, exist_ok=True)
+    install_shims()
+    torch.set_num_threads(1)          # fixed summation order for the captured vectors
+    if a.only in ("", "manifolds"):
+        capture_manifolds(out)
+    if a.only in ("", "layers"):
+        capture_layers(out)
+    if a.only in ("", "diffusion"):
+        capture_diffusion(out)
+
+
+if __name__ == "__main__":
+    main()
