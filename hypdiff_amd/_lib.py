@@ -1,0 +1,98 @@
+"""ctypes binding of libhypdiff_hip.so (declared in include/hypdiff.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  If the
+shared object is missing, `load()` raises and every op built on it fails loudly.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhypdiff_hip.so")
+
+
+class HdCurv(ctypes.Structure):
+    """struct hd_curv of include/hypdiff.h"""
+    _fields_ = [("c", c_double), ("sqrt_c", c_double), ("K", c_double), ("sqrt_K", c_double)]
+
+
+P = c_void_p
+I64 = c_int64
+_map1 = [P, P, I64, I64, HdCurv, P]
+_map2 = [P, P, P, I64, I64, HdCurv, P]
+_at = [P, P, I64, P, P, I64, I64, HdCurv, P]
+_act = [P, P, I64, I64, HdCurv, HdCurv, c_int, P]
+_agg = [P, P, P, P, P, I64, I64, HdCurv, HdCurv, c_int, c_int, P]
+
+# name -> argtypes; names ending in "*" exist as _f32 and _f64
+SIGNATURES = {
+    "hd_pb_proj*": _map1, "hd_pb_expmap0*": _map1, "hd_pb_logmap0*": _map1, "hd_pb_expmap0_proj*": _map1,
+    "hd_pb_mobius_add*": _map2, "hd_pb_expmap*": _map2, "hd_pb_logmap*": _map2,
+    "hd_pb_logmap_at*": _at, "hd_pb_expmap_at*": _at, "hd_pb_sqdist*": _map2,
+    "hd_pb_matvec_epilogue*": [P, P, P, I64, I64, HdCurv, c_int, P],
+    "hd_pb_hyp_act*": _act,
+    "hd_hb_proj*": _map1, "hd_hb_proj_tan0*": _map1, "hd_hb_expmap0*": _map1, "hd_hb_logmap0*": _map1,
+    "hd_hb_expmap0_proj*": _map1, "hd_hb_sqdist*": _map2,
+    "hd_hb_linear_epilogue*": [P, P, I64, I64, HdCurv, c_int, P],
+    "hd_hb_hyp_act*": _act,
+    "hd_rownorm*": [P, P, I64, I64, P],
+    "hd_csr_from_coo": [P, P, I64, I64, I64, P, P, P, P],
+    "hd_spmm_csr*": [P, P, P, P, P, I64, I64, P],
+    "hd_pb_agg*": _agg, "hd_hb_agg*": _agg,
+    "hd_gemm_f32": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, c_int, P],
+    "hd_gemm_f64": [P, P, P, P, I64, I64, I64, I64, I64, I64, P],
+    "hd_q_sample": [P, c_int, P, c_int, P, P, P, I64, P, P, I64, P, I64, I64, c_int, c_double, c_double,
+                    c_double, P],
+    "hd_p_sample_update": [P, c_int, P, P, P, I64, c_double, c_double, c_double, c_double, I64, I64, P, I64,
+                           I64, c_double, c_double, c_double, P],
+    "hd_tran_direction": [P, c_int, P, P, I64, I64, I64, P],
+    "hd_mlp_pack_input": [P, c_int, P, c_int, c_double, P, I64, I64, I64, P],
+    "hd_moments": [P, c_int, I64, P, P, P],
+    "hd_standardize": [P, P, c_int, I64, P, c_int, P],
+}
+
+_lib = None
+
+
+def exported_names():
+    out = ["hd_version", "hd_last_error", "hd_moments_workspace_doubles"]
+    for k in SIGNATURES:
+        out += [k[:-1] + "_f32", k[:-1] + "_f64"] if k.endswith("*") else [k]
+    return out
+
+
+def load():
+    """Load the HIP library once; raise if it is not built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `make -C hypdiff_amd/csrc` "
+            "(or __graft_entry__.build()). hypdiff_amd has no CPU/eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.hd_version.restype = c_int
+    lib.hd_last_error.argtypes = [c_char_p, c_size_t]
+    lib.hd_last_error.restype = c_size_t
+    lib.hd_moments_workspace_doubles.restype = c_int64
+    for key, args in SIGNATURES.items():
+        names = [key[:-1] + "_f32", key[:-1] + "_f64"] if key.endswith("*") else [key]
+        for n in names:
+            fn = getattr(lib, n)
+            fn.argtypes = args
+            fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def last_error():
+    buf = ctypes.create_string_buffer(512)
+    load().hd_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def call(name, *args):
+    """Invoke an entry point; a non-zero status becomes a RuntimeError."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (status {rc}): {last_error()}")

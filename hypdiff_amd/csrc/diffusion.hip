@@ -1,0 +1,256 @@
+// Direction-diffusion step kernels (models/direction_diffusion.py of the reference).
+// All are single-pass elementwise / reduction kernels bound by HBM bandwidth.  dtype
+// promotion follows the reference: schedule tables fp64, getpri fp32, denoiser fp32,
+// so q_sample / p_sample outputs are fp64 whatever the input dtype.
+#include "hd_manifold.cuh"
+#include "../../include/hypdiff.h"
+
+using namespace hd;
+
+namespace {
+
+// getpri, :191-196 -- int64 t times a python float is an fp32 tensor in torch
+__device__ __forceinline__ float getpri(int64_t t, float sqrt_c, float horizon, float prior) {
+    return prior * tanhf(sqrt_c * (float)t / horizon);
+}
+
+__device__ __forceinline__ double ld(const void* p, int dtype, int64_t i) {
+    return dtype ? ((const double*)p)[i] : (double)((const float*)p)[i];
+}
+
+// q_sample, :198-213 (+ tran_direction :154-163 in place on noise when restrict)
+template <typename TX, typename TN>
+__global__ __launch_bounds__(256) void q_sample_k(const TX* __restrict__ x0, TN* __restrict__ noise,
+                                                  const int64_t* __restrict__ t, const int32_t* __restrict__ labels,
+                                                  const float* __restrict__ signs, int64_t n_centres,
+                                                  const double* __restrict__ sqrt_ac,
+                                                  const double* __restrict__ sqrt_1mac, int64_t T,
+                                                  double* __restrict__ out, int64_t rows, int64_t dim,
+                                                  int restrict_, float sqrt_c, float horizon, float prior) {
+    const int64_t total = rows * dim;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / dim, c = i - r * dim;
+        int64_t tt = t[r];
+        tt = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
+        TN nz = noise[i];
+        if (restrict_) {
+            int32_t lb = labels[r];
+            lb = lb < 0 ? 0 : (lb >= n_centres ? (int32_t)n_centres - 1 : lb);
+            nz = (TN)(nz * (TN)signs[(int64_t)lb * dim + c]);
+            noise[i] = nz;
+        }
+        const TX x = x0[i];
+        const float pri = getpri(t[r], sqrt_c, horizon, prior);
+        // pri * x_start is evaluated in the promoted dtype of (fp32, TX)
+        const double px = sizeof(TX) == 4 ? (double)(pri * (float)x) : (double)pri * (double)x;
+        out[i] = sqrt_ac[tt] * (double)x + sqrt_1mac[tt] * (double)nz + px;
+    }
+}
+
+// p_sample after the denoiser, :248-291:
+//   eps = ((sqrt(1/acp_t) + pri_t) * x_t - x0_raw) / sqrt(1/acp_t - 1)     (:230-236, unclamped x0)
+//   x0  = clamp(x0_raw, -1, 1)                                           (:266-267, in place)
+//   eps *= sign(direction[label])                                        (:289 -> :201)
+//   out = sqrt(acp_t2) * x0 + sqrt(1-acp_t2) * eps + pri_t2 * x0          (:212-213)
+template <typename TX>
+__global__ __launch_bounds__(256) void p_sample_update_k(const TX* __restrict__ xt, float* __restrict__ x0,
+                                                         const int32_t* __restrict__ labels,
+                                                         const float* __restrict__ signs, int64_t n_centres,
+                                                         double ra, double rm1, double a2, double b2, float pri_t,
+                                                         float pri_t2, double* __restrict__ out, int64_t rows,
+                                                         int64_t dim) {
+    const int64_t total = rows * dim;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / dim, c = i - r * dim;
+        int32_t lb = labels[r];
+        lb = lb < 0 ? 0 : (lb >= n_centres ? (int32_t)n_centres - 1 : lb);
+        const float raw = x0[i];
+        double eps = ((ra + (double)pri_t) * (double)xt[i] - (double)raw) / rm1;
+        eps = eps * (double)signs[(int64_t)lb * dim + c];
+        const float xc = raw < -1.f ? -1.f : (raw > 1.f ? 1.f : raw);
+        x0[i] = xc;
+        out[i] = a2 * (double)xc + b2 * eps + (double)(pri_t2 * xc);
+    }
+}
+
+// tran_direction, :154-163: noise[i] *= sign(direction[labels[i]]) in place
+template <typename TN>
+__global__ __launch_bounds__(256) void tran_direction_k(TN* __restrict__ noise, const int32_t* __restrict__ labels,
+                                                        const float* __restrict__ signs, int64_t n_centres,
+                                                        int64_t rows, int64_t dim) {
+    const int64_t total = rows * dim;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / dim, c = i - r * dim;
+        int32_t lb = labels[r];
+        lb = lb < 0 ? 0 : (lb >= n_centres ? (int32_t)n_centres - 1 : lb);
+        noise[i] = (TN)(noise[i] * (TN)signs[(int64_t)lb * dim + c]);
+    }
+}
+
+// mlp input: cat(x.float(), t[:,None]).float()  (:57-58), row pitch ld >= dim+1, zero padded
+template <typename TX>
+__global__ __launch_bounds__(256) void pack_input_k(const TX* __restrict__ x, const void* __restrict__ t, int t_kind,
+                                                    float t_scalar, float* __restrict__ out, int64_t rows,
+                                                    int64_t dim, int64_t ldo) {
+    const int64_t total = rows * ldo;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / ldo, c = i - r * ldo;
+        float v = 0.f;
+        if (c < dim) v = (float)x[r * dim + c];
+        else if (c == dim) v = t_kind == 0 ? (float)((const int64_t*)t)[r] : (t_kind == 1 ? ((const float*)t)[r] : t_scalar);
+        out[i] = v;
+    }
+}
+
+constexpr int kMomentBlocks = 1024;
+
+template <typename TX>
+__global__ __launch_bounds__(256) void moments_partial_k(const TX* __restrict__ x, int64_t count,
+                                                         double* __restrict__ ws) {
+    __shared__ double s1[4], s2[4];
+    double a = 0.0, b = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        const double v = (double)x[i];
+        a += v;
+        b += v * v;
+    }
+    a = group_sum<64>(a);
+    b = group_sum<64>(b);
+    if ((threadIdx.x & 63) == 0) { s1[threadIdx.x >> 6] = a; s2[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ws[2 * blockIdx.x] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+        ws[2 * blockIdx.x + 1] = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void moments_final_k(const double* __restrict__ ws, int nblocks,
+                                                       double* __restrict__ out, double count) {
+    __shared__ double s1[4], s2[4];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) { a += ws[2 * i]; b += ws[2 * i + 1]; }
+    a = group_sum<64>(a);
+    b = group_sum<64>(b);
+    if ((threadIdx.x & 63) == 0) { s1[threadIdx.x >> 6] = a; s2[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+        out[1] = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+        out[2] = count;
+    }
+}
+
+// normalization / renormal, :145-153: global mean and UNBIASED std from (sum, sumsq, count)
+template <typename TX>
+__global__ __launch_bounds__(256) void standardize_k(const TX* __restrict__ x, TX* __restrict__ out, int64_t count,
+                                                     const double* __restrict__ m, int inverse) {
+    const double n = m[2], mean = m[0] / n;
+    const double var = (m[1] - m[0] * m[0] / n) / (n - 1.0);
+    const double sd = sqrt(var > 0.0 ? var : 0.0);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        const double v = (double)x[i];
+        out[i] = (TX)(inverse ? v * sd + mean : (v - mean) / sd);
+    }
+}
+
+inline int ew_grid(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    if (b < 1) b = 1;
+    return (int)(b < 256 * 32 ? b : 256 * 32);
+}
+
+}  // namespace
+
+extern "C" int hd_q_sample(const void* x0, int x_dtype, void* noise, int noise_dtype, const int64_t* t,
+                           const int32_t* labels, const float* signs, int64_t n_centres, const double* sqrt_ac,
+                           const double* sqrt_1mac, int64_t T, double* out, int64_t rows, int64_t dim,
+                           int restrict_, double sqrt_c, double horizon, double prior, void* st) {
+    HD_REQUIRE(rows >= 0 && dim >= 1 && T >= 1, "hd_q_sample: bad shape rows=%lld dim=%lld T=%lld", (long long)rows,
+               (long long)dim, (long long)T);
+    if (rows == 0) return HD_OK;
+    HD_REQUIRE(x0 && noise && t && sqrt_ac && sqrt_1mac && out, "hd_q_sample: null pointer");
+    HD_REQUIRE(!restrict_ || (labels && signs && n_centres >= 1), "hd_q_sample: restrict needs labels and signs");
+    const int g = ew_grid(rows * dim);
+    hipStream_t s = (hipStream_t)st;
+#define QS(TX, TN)                                                                                               \
+    q_sample_k<TX, TN><<<g, 256, 0, s>>>((const TX*)x0, (TN*)noise, t, labels, signs, n_centres, sqrt_ac, sqrt_1mac, \
+                                         T, out, rows, dim, restrict_, (float)sqrt_c, (float)horizon, (float)prior)
+    if (!x_dtype && !noise_dtype) QS(float, float);
+    else if (!x_dtype && noise_dtype) QS(float, double);
+    else if (x_dtype && !noise_dtype) QS(double, float);
+    else QS(double, double);
+#undef QS
+    return check_launch("hd_q_sample");
+}
+
+extern "C" int hd_p_sample_update(const void* x_t, int x_dtype, float* x0, const int32_t* labels,
+                                  const float* signs, int64_t n_centres, double sqrt_recip_t,
+                                  double sqrt_recipm1_t, double sqrt_ac_t2, double sqrt_1mac_t2, int64_t t,
+                                  int64_t t2, double* out, int64_t rows, int64_t dim, double sqrt_c,
+                                  double horizon, double prior, void* st) {
+    HD_REQUIRE(rows >= 0 && dim >= 1, "hd_p_sample_update: bad shape");
+    if (rows == 0) return HD_OK;
+    HD_REQUIRE(x_t && x0 && labels && signs && out && n_centres >= 1, "hd_p_sample_update: null pointer");
+    // fp32 prior of a scalar step, same expression as the per-row kernel path
+    const float pri_t = (float)prior * tanhf((float)sqrt_c * (float)t / (float)horizon);
+    const float pri_t2 = (float)prior * tanhf((float)sqrt_c * (float)t2 / (float)horizon);
+    const int g = ew_grid(rows * dim);
+    if (x_dtype)
+        p_sample_update_k<double><<<g, 256, 0, (hipStream_t)st>>>((const double*)x_t, x0, labels, signs, n_centres,
+                                                                  sqrt_recip_t, sqrt_recipm1_t, sqrt_ac_t2,
+                                                                  sqrt_1mac_t2, pri_t, pri_t2, out, rows, dim);
+    else
+        p_sample_update_k<float><<<g, 256, 0, (hipStream_t)st>>>((const float*)x_t, x0, labels, signs, n_centres,
+                                                                 sqrt_recip_t, sqrt_recipm1_t, sqrt_ac_t2,
+                                                                 sqrt_1mac_t2, pri_t, pri_t2, out, rows, dim);
+    return check_launch("hd_p_sample_update");
+}
+
+extern "C" int hd_tran_direction(void* noise, int noise_dtype, const int32_t* labels, const float* signs,
+                                 int64_t n_centres, int64_t rows, int64_t dim, void* st) {
+    HD_REQUIRE(rows >= 0 && dim >= 1, "hd_tran_direction: bad shape");
+    if (rows == 0) return HD_OK;
+    HD_REQUIRE(noise && labels && signs && n_centres >= 1, "hd_tran_direction: null pointer");
+    const int g = ew_grid(rows * dim);
+    if (noise_dtype) tran_direction_k<double><<<g, 256, 0, (hipStream_t)st>>>((double*)noise, labels, signs, n_centres, rows, dim);
+    else tran_direction_k<float><<<g, 256, 0, (hipStream_t)st>>>((float*)noise, labels, signs, n_centres, rows, dim);
+    return check_launch("hd_tran_direction");
+}
+
+extern "C" int hd_mlp_pack_input(const void* x, int x_dtype, const void* t, int t_kind, double t_scalar, float* out,
+                                 int64_t rows, int64_t dim, int64_t ld_out, void* st) {
+    HD_REQUIRE(rows >= 0 && dim >= 1 && ld_out >= dim + 1, "hd_mlp_pack_input: bad shape");
+    if (rows == 0) return HD_OK;
+    HD_REQUIRE(x && out && (t || t_kind == 2) && t_kind >= 0 && t_kind <= 2, "hd_mlp_pack_input: bad argument");
+    const int g = ew_grid(rows * ld_out);
+    if (x_dtype)
+        pack_input_k<double><<<g, 256, 0, (hipStream_t)st>>>((const double*)x, t, t_kind, (float)t_scalar, out, rows, dim, ld_out);
+    else
+        pack_input_k<float><<<g, 256, 0, (hipStream_t)st>>>((const float*)x, t, t_kind, (float)t_scalar, out, rows, dim, ld_out);
+    return check_launch("hd_mlp_pack_input");
+}
+
+extern "C" int64_t hd_moments_workspace_doubles(void) { return 2 * kMomentBlocks; }
+
+extern "C" int hd_moments(const void* x, int dtype, int64_t count, double* workspace, double* out3, void* st) {
+    HD_REQUIRE(count >= 1 && x && workspace && out3, "hd_moments: bad argument");
+    int64_t nb = (count + 255) / 256;
+    nb = nb < kMomentBlocks ? nb : kMomentBlocks;
+    if (dtype) moments_partial_k<double><<<(int)nb, 256, 0, (hipStream_t)st>>>((const double*)x, count, workspace);
+    else moments_partial_k<float><<<(int)nb, 256, 0, (hipStream_t)st>>>((const float*)x, count, workspace);
+    int rc = check_launch("hd_moments(partial)");
+    if (rc) return rc;
+    moments_final_k<<<1, 256, 0, (hipStream_t)st>>>(workspace, (int)nb, out3, (double)count);
+    return check_launch("hd_moments(final)");
+}
+
+extern "C" int hd_standardize(const void* x, void* out, int dtype, int64_t count, const double* moments3,
+                              int inverse, void* st) {
+    HD_REQUIRE(count >= 0, "hd_standardize: bad count");
+    if (count == 0) return HD_OK;
+    HD_REQUIRE(x && out && moments3, "hd_standardize: null pointer");
+    const int g = ew_grid(count);
+    if (dtype) standardize_k<double><<<g, 256, 0, (hipStream_t)st>>>((const double*)x, (double*)out, count, moments3, inverse);
+    else standardize_k<float><<<g, 256, 0, (hipStream_t)st>>>((const float*)x, (float*)out, count, moments3, inverse);
+    return check_launch("hd_standardize");
+}

@@ -1,0 +1,207 @@
+// Device-side manifold maps on register-resident row tiles.
+//
+// Each function restates one method of the reference (file:line in the comment)
+// with the same clamp order and the same dtype rules: arithmetic in the row's
+// dtype T, artanh/arcosh evaluated in fp64 and cast back
+// (utils/math_utils.py:30-36,57-63), eps chosen by dtype
+// (manifolds/poincare.py:23, manifolds/hyperboloid.py:21).
+#pragma once
+#include "hd_common.cuh"
+
+namespace hd {
+
+template <typename T> struct Lim;
+template <> struct Lim<float> {
+    static constexpr double pb_eps = 4e-3, hb_eps = 1e-7;
+};
+template <> struct Lim<double> {
+    static constexpr double pb_eps = 1e-5, hb_eps = 1e-15;
+};
+
+constexpr double kMinNorm = 1e-15;
+
+template <typename T> __device__ __forceinline__ T clamp_min(T x, T lo) { return x < lo ? lo : x; }
+template <typename T> __device__ __forceinline__ T clamp_max(T x, T hi) { return x > hi ? hi : x; }
+template <typename T> __device__ __forceinline__ T clamp15(T x) {
+    return x < T(-15) ? T(-15) : (x > T(15) ? T(15) : x);
+}
+__device__ __forceinline__ float hd_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double hd_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float hd_tanh(float x) { return tanhf(x); }
+__device__ __forceinline__ double hd_tanh(double x) { return tanh(x); }
+__device__ __forceinline__ float hd_cosh(float x) { return coshf(x); }
+__device__ __forceinline__ double hd_cosh(double x) { return cosh(x); }
+__device__ __forceinline__ float hd_sinh(float x) { return sinhf(x); }
+__device__ __forceinline__ double hd_sinh(double x) { return sinh(x); }
+
+// utils/math_utils.py:14-15
+template <typename T> __device__ __forceinline__ T tanh15(T x) { return hd_tanh(clamp15(x)); }
+template <typename T> __device__ __forceinline__ T cosh15(T x) { return hd_cosh(clamp15(x)); }
+template <typename T> __device__ __forceinline__ T sinh15(T x) { return hd_sinh(clamp15(x)); }
+
+// utils/math_utils.py:30-36: clamp to [-1+1e-15, 1-1e-15] in T (a no-op bound in fp32),
+// then 0.5*(log(1+z) - log(1-z)) in fp64, cast back to T.
+template <typename T> __device__ __forceinline__ T artanh_ref(T x) {
+    const T lo = (T)(-1.0 + 1e-15), hi = (T)(1.0 - 1e-15);
+    x = x < lo ? lo : (x > hi ? hi : x);
+    const double z = (double)x;
+    return (T)(0.5 * (log(1.0 + z) - log(1.0 - z)));
+}
+// utils/math_utils.py:57-63
+template <typename T> __device__ __forceinline__ T arcosh_ref(T x) {
+    const T lo = (T)(1.0 + 1e-15);
+    x = x < lo ? lo : x;
+    const double z = (double)x;
+    double a = z + sqrt(z * z - 1.0);
+    a = a < 1e-15 ? 1e-15 : a;
+    return (T)log(a);
+}
+
+// ================================ Poincare ball ================================
+template <typename T> struct PB {
+    // manifolds/poincare.py:42-47
+    template <class TL> static __device__ __forceinline__ void proj(TL& r, const Curv& cv) {
+        const T n = clamp_min(hd_sqrt(r.sumsq()), (T)kMinNorm);
+        const T maxnorm = (T)((1.0 - Lim<T>::pb_eps) / cv.sc);
+        if (n > maxnorm) r.map([=](T x) { return x / n * maxnorm; });
+    }
+    // manifolds/poincare.py:73-77
+    template <class TL> static __device__ __forceinline__ void expmap0(TL& r, const Curv& cv) {
+        const T sc = (T)cv.sc;
+        const T n = clamp_min(hd_sqrt(r.sumsq()), (T)kMinNorm);
+        const T th = tanh15(sc * n), den = sc * n;
+        r.map([=](T x) { return th * x / den; });
+    }
+    // manifolds/poincare.py:79-83
+    template <class TL> static __device__ __forceinline__ void logmap0(TL& r, const Curv& cv) {
+        const T sc = (T)cv.sc;
+        const T n = clamp_min(hd_sqrt(r.sumsq()), (T)kMinNorm);
+        const T f = T(1) / sc * artanh_ref(sc * n) / n;
+        r.scale(f);
+    }
+    // manifolds/poincare.py:85-91 : x <- x (+) y
+    template <class TL> static __device__ __forceinline__ void mobius_add(TL& x, const TL& y, const Curv& cv) {
+        const T c = (T)cv.c;
+        const T x2 = x.sumsq(), y2 = y.sumsq(), xy = x.dot(y);
+        const T a = T(1) + T(2) * c * xy + c * y2;
+        const T b = T(1) - c * x2;
+        const T den = clamp_min(T(1) + T(2) * c * xy + c * c * x2 * y2, (T)kMinNorm);
+#pragma unroll
+        for (int i = 0; i < kRegs; ++i) x.v[i] = (a * x.v[i] + b * y.v[i]) / den;
+    }
+    // manifolds/poincare.py:33-35
+    template <class TL> static __device__ __forceinline__ T lambda_x(const TL& x, const Curv& cv) {
+        return T(2) / clamp_min(T(1) - (T)cv.c * x.sumsq(), (T)kMinNorm);
+    }
+    // manifolds/poincare.py:55-64 : u <- expmap(u, p)
+    template <class TL> static __device__ __forceinline__ void expmap(TL& u, const TL& p, const Curv& cv) {
+        const T sc = (T)cv.sc;
+        const T un = clamp_min(hd_sqrt(u.sumsq()), (T)kMinNorm);
+        const T th = tanh15(sc / T(2) * lambda_x(p, cv) * un), den = sc * un;
+        u.map([=](T x) { return th * x / den; });
+        TL q = p;
+        mobius_add(q, u, cv);
+        u = q;
+    }
+    // manifolds/poincare.py:66-71 : p2 <- logmap(p1, p2)
+    template <class TL> static __device__ __forceinline__ void logmap(const TL& p1, TL& p2, const Curv& cv) {
+        const T sc = (T)cv.sc;
+        TL s = p1;
+        s.map([](T x) { return -x; });
+        mobius_add(s, p2, cv);
+        const T sn = clamp_min(hd_sqrt(s.sumsq()), (T)kMinNorm);
+        const T lam = lambda_x(p1, cv);
+        const T f = T(2) / sc / lam * artanh_ref(sc * sn);
+        s.map([=](T x) { return f * x / sn; });
+        p2 = s;
+    }
+    // manifolds/poincare.py:25-31
+    template <class TL> static __device__ __forceinline__ T sqdist(const TL& p1, const TL& p2, const Curv& cv) {
+        const T sc = (T)cv.sc;
+        TL s = p1;
+        s.map([](T x) { return -x; });
+        mobius_add(s, p2, cv);
+        const T d = artanh_ref(sc * hd_sqrt(s.sumsq())) * T(2) / sc;
+        return d * d;
+    }
+    // manifolds/poincare.py:93-102 after mx = x @ W^T: r holds mx, xn = clamp_min(|x|)
+    template <class TL> static __device__ __forceinline__ void matvec_epilogue(TL& r, T xn, const Curv& cv) {
+        const T sc = (T)cv.sc;
+        const bool nz = r.any_nonzero();
+        const T mxn = clamp_min(hd_sqrt(r.sumsq()), (T)kMinNorm);
+        const T th = tanh15(mxn / xn * artanh_ref(sc * xn)), den = mxn * sc;
+        if (nz) r.map([=](T x) { return th * x / den; });
+        else r.zero();
+    }
+    template <class TL> static __device__ __forceinline__ void proj_tan0(TL&, const Curv&) {}
+};
+
+// ================================= Hyperboloid =================================
+// Column 0 of every row is the time coordinate.
+template <typename T> struct HB {
+    // manifolds/hyperboloid.py:43-52
+    template <class TL> static __device__ __forceinline__ void proj(TL& r, const Curv& cv) {
+        const T n = hd_sqrt(r.sumsq(1));
+        const T x0 = hd_sqrt(clamp_min((T)cv.K + n * n, (T)Lim<T>::hb_eps));
+        r.set_first(x0);
+    }
+    // manifolds/hyperboloid.py:64-68
+    template <class TL> static __device__ __forceinline__ void proj_tan0(TL& r, const Curv&) {
+        if (r.j == 0) r.v[0] = r.v[0] - r.v[0];
+    }
+    // manifolds/hyperboloid.py:90-101 (ends with proj)
+    template <class TL> static __device__ __forceinline__ void expmap0(TL& r, const Curv& cv) {
+        const T sK = (T)cv.sK;
+        const T n = clamp_min(hd_sqrt(r.sumsq(1)), (T)kMinNorm);
+        const T theta = n / sK;
+        const T sh = sK * sinh15(theta);
+        r.map([=](T x) { return sh * x / n; });
+        r.set_first(sK * cosh15(theta));
+        proj(r, cv);
+    }
+    // manifolds/hyperboloid.py:103-113
+    template <class TL> static __device__ __forceinline__ void logmap0(TL& r, const Curv& cv) {
+        const T sK = (T)cv.sK;
+        const T n = clamp_min(hd_sqrt(r.sumsq(1)), (T)kMinNorm);
+        const T theta = clamp_min(r.first() / sK, (T)(1.0 + Lim<T>::hb_eps));
+        const T f = sK * arcosh_ref(theta);
+        r.map([=](T x) { return f * x / n; });
+        r.set_first(T(0));
+    }
+    // manifolds/hyperboloid.py:35-41
+    template <class TL> static __device__ __forceinline__ T sqdist(const TL& x, const TL& y, const Curv& cv) {
+        const T K = (T)cv.K;
+        const T x0 = x.first(), y0 = y.first();
+        // sum over all columns minus twice the time product (hyperboloid.py:26)
+        const T prod = x.dot(y) - T(2) * x0 * y0;
+        const T theta = clamp_min(-prod / K, (T)(1.0 + Lim<T>::hb_eps));
+        const T a = arcosh_ref(theta);
+        return clamp_max(K * (a * a), T(50));
+    }
+};
+
+// ---- activations applied in the tangent space (layers/hyp_layers.py:171) -------
+enum Act { ACT_IDENTITY = 0, ACT_RELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3, ACT_ELU = 4, ACT_LEAKY_RELU = 5 };
+
+template <typename T> __device__ __forceinline__ T apply_act(T x, int act) {
+    switch (act) {
+        case ACT_RELU: return x > T(0) ? x : (x != x ? x : T(0));
+        case ACT_TANH: return hd_tanh(x);
+        case ACT_SIGMOID: return T(1) / (T(1) + (T)exp((double)-x));
+        case ACT_ELU: return x > T(0) ? x : (T)expm1((double)x);
+        case ACT_LEAKY_RELU: return x > T(0) ? x : T(0.01) * x;
+        default: return x;
+    }
+}
+
+// layers/hyp_layers.py:170-173: logmap0(c_in) -> act -> proj_tan0 -> expmap0(c_out) -> proj(c_out)
+template <class M, typename T, class TL>
+__device__ __forceinline__ void hyp_act(TL& r, const Curv& cin, const Curv& cout, int act) {
+    M::logmap0(r, cin);
+    r.map([=](T x) { return apply_act(x, act); });
+    M::proj_tan0(r, cout);
+    M::expmap0(r, cout);
+    M::proj(r, cout);
+}
+
+}  // namespace hd

@@ -1,0 +1,186 @@
+// Generic row kernels: one group of G lanes per row, row in registers.
+#pragma once
+#include <type_traits>
+#include "hd_manifold.cuh"
+
+namespace hd {
+
+template <int N> using IC = std::integral_constant<int, N>;
+
+// calls f(IC<G>, IC<VEC>) for the configuration picked for (T, d, alignment)
+template <typename T, class F>
+inline int dispatch_cfg(const RowCfg& c, F&& f) {
+    constexpr int V = VecOf<T>::N;
+    if (c.vec == 1) {
+        if (c.g == 4) return f(IC<4>{}, IC<1>{});
+        if (c.g == 16) return f(IC<16>{}, IC<1>{});
+        return f(IC<64>{}, IC<1>{});
+    }
+    if (c.g == 4) return f(IC<4>{}, IC<V>{});
+    if (c.g == 16) return f(IC<16>{}, IC<V>{});
+    return f(IC<64>{}, IC<V>{});
+}
+
+// out[row] = op(in[row])
+template <class Op, typename T, int G, int VEC>
+__global__ __launch_bounds__(kBlock) void row_map1(const T* __restrict__ in, T* __restrict__ out,
+                                                   int64_t n, int d, Op op) {
+    constexpr int RPB = kBlock / G;
+    Tile<T, G, VEC> r;
+    r.init(d);
+    for (int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / G; row < n; row += (int64_t)gridDim.x * RPB) {
+        r.load(in + row * d);
+        op(r, row);
+        r.store(out + row * d);
+    }
+}
+
+// out[row] = op(a[row or gathered], b[row]); ia (optional) gathers rows of a
+template <class Op, typename T, typename I, int G, int VEC>
+__global__ __launch_bounds__(kBlock) void row_map2(const T* __restrict__ a, const I* __restrict__ ia,
+                                                   const T* __restrict__ b, T* __restrict__ out,
+                                                   int64_t n, int d, Op op) {
+    constexpr int RPB = kBlock / G;
+    Tile<T, G, VEC> x, y;
+    x.init(d);
+    y.init(d);
+    for (int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / G; row < n; row += (int64_t)gridDim.x * RPB) {
+        const int64_t ra = ia ? (int64_t)ia[row] : row;
+        x.load(a + ra * d);
+        y.load(b + row * d);
+        op(x, y, row);          // result left in y
+        y.store(out + row * d);
+    }
+}
+
+// out[row] = scalar op(a[row], b[row])
+template <class Op, typename T, int G, int VEC>
+__global__ __launch_bounds__(kBlock) void row_reduce2(const T* __restrict__ a, const T* __restrict__ b,
+                                                      T* __restrict__ out, int64_t n, int d, Op op) {
+    constexpr int RPB = kBlock / G;
+    Tile<T, G, VEC> x, y;
+    x.init(d);
+    y.init(d);
+    for (int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / G; row < n; row += (int64_t)gridDim.x * RPB) {
+        x.load(a + row * d);
+        y.load(b + row * d);
+        const T s = op(x, y);
+        if (x.j == 0) out[row] = s;
+    }
+}
+
+template <typename T, class Op>
+inline int launch_map1(const char* name, const T* in, T* out, int64_t n, int64_t d, Op op, hipStream_t st) {
+    HD_REQUIRE(n >= 0 && d >= 1, "%s: bad shape rows=%lld dim=%lld", name, (long long)n, (long long)d);
+    if (n == 0) return HD_OK;
+    HD_REQUIRE(in && out, "%s: null pointer", name);
+    const RowCfg c = pick_cfg<T>(d, is_aligned16(in) && is_aligned16(out));
+    HD_REQUIRE(c.ok, "%s: dim=%lld exceeds the register-tile limit (use the streaming entry point)", name, (long long)d);
+    return dispatch_cfg<T>(c, [&](auto g, auto v) {
+        constexpr int G = decltype(g)::value, V = decltype(v)::value;
+        row_map1<Op, T, G, V><<<grid_for_rows(n, G), kBlock, 0, st>>>(in, out, n, (int)d, op);
+        return check_launch(name);
+    });
+}
+
+template <typename T, typename I, class Op>
+inline int launch_map2(const char* name, const T* a, const I* ia, const T* b, T* out, int64_t n, int64_t d,
+                       Op op, hipStream_t st) {
+    HD_REQUIRE(n >= 0 && d >= 1, "%s: bad shape rows=%lld dim=%lld", name, (long long)n, (long long)d);
+    if (n == 0) return HD_OK;
+    HD_REQUIRE(a && b && out, "%s: null pointer", name);
+    const RowCfg c = pick_cfg<T>(d, is_aligned16(a) && is_aligned16(b) && is_aligned16(out));
+    HD_REQUIRE(c.ok, "%s: dim=%lld exceeds the register-tile limit", name, (long long)d);
+    return dispatch_cfg<T>(c, [&](auto g, auto v) {
+        constexpr int G = decltype(g)::value, V = decltype(v)::value;
+        row_map2<Op, T, I, G, V><<<grid_for_rows(n, G), kBlock, 0, st>>>(a, ia, b, out, n, (int)d, op);
+        return check_launch(name);
+    });
+}
+
+template <typename T, class Op>
+inline int launch_reduce2(const char* name, const T* a, const T* b, T* out, int64_t n, int64_t d, Op op,
+                          hipStream_t st) {
+    HD_REQUIRE(n >= 0 && d >= 1, "%s: bad shape rows=%lld dim=%lld", name, (long long)n, (long long)d);
+    if (n == 0) return HD_OK;
+    HD_REQUIRE(a && b && out, "%s: null pointer", name);
+    const RowCfg c = pick_cfg<T>(d, is_aligned16(a) && is_aligned16(b));
+    HD_REQUIRE(c.ok, "%s: dim=%lld exceeds the register-tile limit", name, (long long)d);
+    return dispatch_cfg<T>(c, [&](auto g, auto v) {
+        constexpr int G = decltype(g)::value, V = decltype(v)::value;
+        row_reduce2<Op, T, G, V><<<grid_for_rows(n, G), kBlock, 0, st>>>(a, b, out, n, (int)d, op);
+        return check_launch(name);
+    });
+}
+
+// ---- streaming path for rows longer than the register tile ------------------------
+// One wavefront per row, two sweeps: sum of squares, then scale.  The second sweep
+// re-reads the row from L2.  Norms of already scaled rows are taken analytically
+// (|f*x| = |f||x|), which differs from the literal recomputation by rounding only.
+enum StreamOp { S_PB_PROJ = 0, S_PB_EXPMAP0, S_PB_LOGMAP0, S_PB_EXPMAP0_PROJ,
+                S_HB_PROJ, S_HB_EXPMAP0, S_HB_LOGMAP0, S_ROWNORM };
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void row_stream(const T* __restrict__ in, T* __restrict__ out,
+                                                     int64_t n, int64_t d, int op, Curv cv) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
+    const bool hb = (op == S_HB_PROJ || op == S_HB_EXPMAP0 || op == S_HB_LOGMAP0);
+    for (int64_t row = wave; row < n; row += nwaves) {
+        const T* x = in + row * d;
+        T ss = T(0);
+        for (int64_t i = lane + (hb ? 64 : 0); i < d; i += 64) ss += x[i] * x[i];
+        if (hb) {       // first 64 columns without the time coordinate
+            const int64_t i = lane;
+            if (i >= 1 && i < d) ss += x[i] * x[i];
+        }
+        ss = group_sum<64>(ss);
+        const T nrm = hd_sqrt(ss);
+        if (op == S_ROWNORM) {
+            if (lane == 0) out[row] = nrm;
+            continue;
+        }
+        const T n1 = clamp_min(nrm, (T)kMinNorm);
+        T f = T(1), t0 = T(0);
+        bool set_t0 = false;
+        const T maxnorm = (T)((1.0 - Lim<T>::pb_eps) / cv.sc);
+        const T sc = (T)cv.sc, sK = (T)cv.sK;
+        switch (op) {
+            case S_PB_PROJ: f = n1 > maxnorm ? maxnorm / n1 : T(1); break;
+            case S_PB_EXPMAP0: f = tanh15(sc * n1) / (sc * n1); break;
+            case S_PB_LOGMAP0: f = T(1) / sc * artanh_ref(sc * n1) / n1; break;
+            case S_PB_EXPMAP0_PROJ: {
+                f = tanh15(sc * n1) / (sc * n1);
+                const T n2 = clamp_min(f * nrm, (T)kMinNorm);
+                if (n2 > maxnorm) f = f / n2 * maxnorm;
+            } break;
+            case S_HB_PROJ:
+                t0 = hd_sqrt(clamp_min((T)cv.K + nrm * nrm, (T)Lim<T>::hb_eps)); set_t0 = true; break;
+            case S_HB_EXPMAP0: {
+                const T theta = n1 / sK;
+                f = sK * sinh15(theta) / n1;
+                const T n2 = f * nrm;
+                t0 = hd_sqrt(clamp_min((T)cv.K + n2 * n2, (T)Lim<T>::hb_eps)); set_t0 = true;
+            } break;
+            case S_HB_LOGMAP0: {
+                const T theta = clamp_min(x[0] / sK, (T)(1.0 + Lim<T>::hb_eps));
+                f = sK * arcosh_ref(theta) / n1; t0 = T(0); set_t0 = true;
+            } break;
+        }
+        T* y = out + row * d;
+        for (int64_t i = lane; i < d; i += 64) y[i] = (set_t0 && i == 0) ? t0 : x[i] * f;
+    }
+}
+
+template <typename T>
+inline int launch_stream(const char* name, const T* in, T* out, int64_t n, int64_t d, int op, const Curv& cv,
+                         hipStream_t st) {
+    HD_REQUIRE(n >= 0 && d >= 1, "%s: bad shape rows=%lld dim=%lld", name, (long long)n, (long long)d);
+    if (n == 0) return HD_OK;
+    HD_REQUIRE(in && out, "%s: null pointer", name);
+    row_stream<T><<<grid_for_rows(n, 64), kBlock, 0, st>>>(in, out, n, d, op, cv);
+    return check_launch(name);
+}
+
+}  // namespace hd

@@ -1,0 +1,268 @@
+"""Tensor-level wrappers over the C ABI (device pointers in, device tensors out).
+
+PyTorch is plumbing here: it owns the device memory and the stream.  Every function
+enqueues HIP kernels of libhypdiff_hip.so on the current stream and returns without
+synchronising.  Inputs must live on the GPU; nothing here computes on the CPU.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import HdCurv
+
+ACT_CODES = {"identity": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "elu": 4, "leaky_relu": 5}
+
+_curv_cache = {}
+
+
+def curv(c):
+    """hd_curv for a python-float or 1-element-tensor curvature.
+
+    Precision rules of the reference's expressions `c ** 0.5`, `1. / c`, `K ** 0.5`
+    (manifolds/poincare.py:26, manifolds/hyperboloid.py:36-37): double for a python
+    float, the tensor's own dtype for a tensor (layers/hyp_layers.py:35).  Tensor
+    curvatures are read back once per (storage, version) and cached."""
+    if isinstance(c, HdCurv):
+        return c
+    if torch.is_tensor(c):
+        key = (c.data_ptr(), c._version, c.dtype, c.device)
+        hit = _curv_cache.get(key)
+        if hit is None:
+            ch = c.detach().reshape(-1)[:1].cpu()
+            K = 1.0 / ch
+            hit = HdCurv(float(ch), float(ch ** 0.5), float(K), float(K ** 0.5))
+            if len(_curv_cache) > 256:
+                _curv_cache.clear()
+            _curv_cache[key] = hit
+        return hit
+    c = float(c)
+    return HdCurv(c, c ** 0.5, 1.0 / c, (1.0 / c) ** 0.5)
+
+
+def _sfx(t):
+    if t.dtype == torch.float32:
+        return "_f32"
+    if t.dtype == torch.float64:
+        return "_f64"
+    raise TypeError(f"hypdiff_amd kernels take float32/float64 rows, got {t.dtype}")
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("hypdiff_amd runs on the MI355X only: tensor is on %s (no CPU fallback)" % t.device)
+
+
+def _no_grad(*ts):
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts):
+        raise NotImplementedError(
+            "hypdiff_amd round 1 ships forward kernels only; call under torch.no_grad() "
+            "(backward kernels are the next row of the build plan)")
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _rows(x):
+    """View x as contiguous (rows, dim); returns (x2d, original shape)."""
+    shape = x.shape
+    x2 = x.reshape(-1, shape[-1]) if x.dim() != 2 else x
+    return x2.contiguous(), shape
+
+
+def map1(name, x, c):
+    _dev(x); _no_grad(x)
+    x2, shape = _rows(x)
+    out = torch.empty_like(x2)
+    _lib.call(name + _sfx(x2), _p(x2), _p(out), x2.shape[0], x2.shape[1], curv(c), _stream())
+    return out.view(shape)
+
+
+def map2(name, a, b, c):
+    """Row-wise binary map; a and b broadcast against each other like torch would."""
+    _dev(a, b); _no_grad(a, b)
+    if a.dtype != b.dtype:
+        dt = torch.promote_types(a.dtype, b.dtype)
+        a, b = a.to(dt), b.to(dt)
+    if a.shape != b.shape:
+        a, b = torch.broadcast_tensors(a, b)
+    a2, shape = _rows(a)
+    b2, _ = _rows(b)
+    out = torch.empty_like(a2)
+    _lib.call(name + _sfx(a2), _p(a2), _p(b2), _p(out), a2.shape[0], a2.shape[1], curv(c), _stream())
+    return out.view(shape)
+
+
+def sqdist(name, a, b, c):
+    _dev(a, b); _no_grad(a, b)
+    if a.dtype != b.dtype:
+        dt = torch.promote_types(a.dtype, b.dtype)
+        a, b = a.to(dt), b.to(dt)
+    a2, shape = _rows(a)
+    b2, _ = _rows(b)
+    out = torch.empty(a2.shape[0], dtype=a2.dtype, device=a2.device)
+    _lib.call(name + _sfx(a2), _p(a2), _p(b2), _p(out), a2.shape[0], a2.shape[1], curv(c), _stream())
+    return out.view(shape[:-1])
+
+
+def map_at(name, centres, labels_dev, x, c):
+    """logmap/expmap with the base point gathered per row: centres[labels[row]]."""
+    _dev(centres, labels_dev, x); _no_grad(centres, x)
+    x2, shape = _rows(x)
+    ce = centres.to(x2.dtype).contiguous()
+    out = torch.empty_like(x2)
+    _lib.call(name + _sfx(x2), _p(ce), _p(labels_dev), ce.shape[0], _p(x2), _p(out), x2.shape[0], x2.shape[1],
+              curv(c), _stream())
+    return out.view(shape)
+
+
+def hyp_act(manifold, x, c_in, c_out, act_code):
+    _dev(x); _no_grad(x)
+    x2, shape = _rows(x)
+    out = torch.empty_like(x2)
+    _lib.call(f"hd_{manifold}_hyp_act" + _sfx(x2), _p(x2), _p(out), x2.shape[0], x2.shape[1], curv(c_in),
+              curv(c_out), act_code, _stream())
+    return out.view(shape)
+
+
+def rownorm(x2):
+    out = torch.empty(x2.shape[0], dtype=x2.dtype, device=x2.device)
+    _lib.call("hd_rownorm" + _sfx(x2), _p(x2), _p(out), x2.shape[0], x2.shape[1], _stream())
+    return out
+
+
+def _pad_k(t, k_pad):
+    """zero-pad the last dim of a 2-D tensor to k_pad columns (16-byte rows for the GEMM)"""
+    if t.shape[1] == k_pad and t.is_contiguous() and t.data_ptr() % 16 == 0:
+        return t
+    out = torch.zeros(t.shape[0], k_pad, dtype=t.dtype, device=t.device)
+    out[:, : t.shape[1]] = t
+    return out
+
+
+def gemm(a, w, bias=None, epi=0, resid=None, out=None):
+    """epi(a @ w.T + bias): fp32 on the exact-f32 matrix cores, fp64 on the vector ALU."""
+    _dev(a, w, bias)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K, (a.shape, w.shape)
+    if out is None:
+        out = torch.empty(M, N, dtype=a.dtype, device=a.device)
+    if a.dtype == torch.float64:
+        assert epi == 0
+        a, w = a.contiguous(), w.contiguous()
+        _lib.call("hd_gemm_f64", _p(a), _p(w), _p(bias), _p(out), M, N, K, K, K, out.stride(0), _stream())
+        return out
+    if K % 4:
+        kp = (K + 3) // 4 * 4
+        a, w = _pad_k(a, kp), _pad_k(w, kp)
+    a = a if a.stride(1) == 1 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 else a.contiguous()
+    w = w if w.stride(1) == 1 and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0 else w.contiguous()
+    _lib.call("hd_gemm_f32", _p(a), _p(w), _p(bias), _p(resid), _p(out), M, N, a.shape[1], a.stride(0),
+              w.stride(0), out.stride(0), epi, _stream())
+    return out
+
+
+# ---- adjacency -------------------------------------------------------------------
+class CSR:
+    """Device CSR (int32 rowptr/col, values in the COO's dtype and entry order)."""
+
+    def __init__(self, rowptr, col, val, shape):
+        self.rowptr, self.col, self.val, self.shape = rowptr, col, val, shape
+
+    def values(self, dtype):
+        return self.val if self.val.dtype == dtype else self.val.to(dtype)
+
+
+def csr_from_coo(indices, values, shape):
+    """COO (int64 (2,nnz) indices) -> CSR on the GPU (hd_csr_from_coo).  The reference's
+    adjacency is row-sorted (utils/data_utils.py:125-133); an unsorted COO is first
+    ordered by row with a stable device sort (plumbing), then bucketed by the same kernel."""
+    _dev(indices, values)
+    n_rows, n_cols = int(shape[0]), int(shape[1])
+    nnz = indices.shape[1]
+    dev = indices.device
+    row = indices[0].contiguous().to(torch.int64)
+    colin = indices[1].contiguous().to(torch.int64)
+    for attempt in range(2):
+        rowptr = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
+        col = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+        flags = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.call("hd_csr_from_coo", _p(row), _p(colin), nnz, n_rows, n_cols, _p(rowptr), _p(col), _p(flags),
+                  _stream())
+        f = int(flags.item())
+        if f & 2:
+            raise IndexError("adjacency index out of range for shape %s" % (tuple(shape),))
+        if not (f & 1):
+            return CSR(rowptr, col[:nnz], values.contiguous(), (n_rows, n_cols))
+        order = torch.sort(row, stable=True).indices
+        row, colin, values = row[order], colin[order], values[order]
+    raise RuntimeError("hd_csr_from_coo: COO still unsorted after a stable sort")
+
+
+def csr_of(adj):
+    """CSR of a torch sparse COO adjacency, built once and kept on the tensor object."""
+    if isinstance(adj, CSR):
+        return adj
+    cached = getattr(adj, "_hd_csr", None)
+    if cached is not None:
+        return cached
+    if not adj.is_sparse:
+        raise TypeError("HypAgg expects a torch sparse COO adjacency (utils/data_utils.py:125-133)")
+    csr = csr_from_coo(adj._indices(), adj._values(), adj.shape)
+    try:
+        adj._hd_csr = csr
+    except Exception:
+        pass
+    return csr
+
+
+def spmm(csr, x):
+    _dev(x)
+    x2 = x.contiguous()
+    out = torch.empty(csr.shape[0], x2.shape[1], dtype=x2.dtype, device=x2.device)
+    _lib.call("hd_spmm_csr" + _sfx(x2), _p(csr.rowptr), _p(csr.col), _p(csr.values(x2.dtype)), _p(x2), _p(out),
+              csr.shape[0], x2.shape[1], _stream())
+    return out
+
+
+def agg(manifold, csr, xt, c_in, c_out=None, act_code=None):
+    """proj(expmap0(spmm(adj, xt))) [+ HypAct when act_code is given], one kernel."""
+    _dev(xt)
+    x2 = xt.contiguous()
+    if csr.shape[1] != x2.shape[0]:
+        raise ValueError(f"adjacency {csr.shape} does not match {tuple(x2.shape)} rows")
+    out = torch.empty(csr.shape[0], x2.shape[1], dtype=x2.dtype, device=x2.device)
+    fuse = act_code is not None
+    _lib.call(f"hd_{manifold}_agg" + _sfx(x2), _p(csr.rowptr), _p(csr.col), _p(csr.values(x2.dtype)), _p(x2),
+              _p(out), csr.shape[0], x2.shape[1], curv(c_in), curv(c_out if fuse else c_in),
+              act_code if fuse else 0, 1 if fuse else 0, _stream())
+    return out
+
+
+# ---- labels / sign tables ----------------------------------------------------------
+_label_cache = {}
+
+
+def labels_dev(labels, device):
+    """int32 device copy of the host label array (the reference indexes python lists
+    with it row by row, models/direction_diffusion.py:159); cached by content."""
+    if torch.is_tensor(labels):
+        return labels.to(device=device, dtype=torch.int32).contiguous()
+    arr = np.ascontiguousarray(np.asarray(labels).reshape(-1))
+    key = (id(labels), str(device))
+    hit = _label_cache.get(key)
+    if hit is not None and hit[0].shape == arr.shape and np.array_equal(hit[0], arr):
+        return hit[1]
+    t = torch.from_numpy(arr.astype(np.int32)).to(device)
+    if len(_label_cache) > 64:
+        _label_cache.clear()
+    _label_cache[key] = (arr.copy(), t)
+    return t

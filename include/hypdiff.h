@@ -1,0 +1,170 @@
+/* hypdiff.h -- C ABI of libhypdiff_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the hyperbolic encode + direction-diffusion hot path of
+ * RingBDStack/HypDiff.  The reference is pure Python on PyTorch and has no FFI of
+ * its own; each entry point below replaces the chain of aten launches behind ONE
+ * reference method (cited as file:line relative to the reference root).  The
+ * Python classes in hypdiff_amd/ bind these symbols with ctypes.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer into memory owned by the caller (PyTorch);
+ *    the library never allocates, frees or retains them, and never synchronises;
+ *  - matrices are dense row-major and contiguous: (rows, dim), row stride = dim;
+ *  - `_f32` / `_f64` suffix = element type of the row data;
+ *  - `stream` is a hipStream_t (NULL = default stream); work is only enqueued;
+ *  - return 0 on success, non-zero on failure (1 bad argument, 2 HIP error,
+ *    3 unsupported); hd_last_error() returns the message of the calling thread's
+ *    last failure.  No C++ exception crosses the boundary;
+ *  - thread-safe and re-entrant: no global mutable state besides the per-thread
+ *    error string.
+ */
+#ifndef HYPDIFF_H
+#define HYPDIFF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Curvature bundle, computed by the host with the reference's precision rules:
+ * c, c**0.5, K = 1/c, K**0.5 (a python-float c in double; a 1-element tensor c in
+ * the tensor's dtype -- layers/hyp_layers.py:35, models/base_models.py:24). */
+typedef struct hd_curv {
+    double c, sqrt_c, K, sqrt_K;
+} hd_curv;
+
+/* activation codes for the tangent-space activation of HypAct */
+enum { HD_ACT_IDENTITY = 0, HD_ACT_RELU = 1, HD_ACT_TANH = 2, HD_ACT_SIGMOID = 3, HD_ACT_ELU = 4,
+       HD_ACT_LEAKY_RELU = 5 };
+
+int hd_version(void);
+/* copies the calling thread's last error message (NUL-terminated) into buf */
+size_t hd_last_error(char* buf, size_t cap);
+
+#define HD_DECL2(name, ...) int name##_f32(__VA_ARGS__); int name##_f64(__VA_ARGS__);
+
+/* ---- Poincare ball, manifolds/poincare.py ------------------------------------- */
+/* proj :42-47 */
+HD_DECL2(hd_pb_proj, const void* x, void* out, int64_t rows, int64_t dim, hd_curv c, void* stream)
+/* expmap0 :73-77 */
+HD_DECL2(hd_pb_expmap0, const void* u, void* out, int64_t rows, int64_t dim, hd_curv c, void* stream)
+/* logmap0 :79-83 (artanh in fp64, utils/math_utils.py:30-36) */
+HD_DECL2(hd_pb_logmap0, const void* p, void* out, int64_t rows, int64_t dim, hd_curv c, void* stream)
+/* proj(expmap0(proj_tan0(x))) -- the input lift of models/encoders.py:115-119 in one pass */
+HD_DECL2(hd_pb_expmap0_proj, const void* u, void* out, int64_t rows, int64_t dim, hd_curv c, void* stream)
+/* mobius_add :85-91 */
+HD_DECL2(hd_pb_mobius_add, const void* x, const void* y, void* out, int64_t rows, int64_t dim, hd_curv c,
+         void* stream)
+/* expmap(u, p) :55-64 -- first pointer is the base point p, second the tangent u */
+HD_DECL2(hd_pb_expmap, const void* p, const void* u, void* out, int64_t rows, int64_t dim, hd_curv c,
+         void* stream)
+/* logmap(p1, p2) :66-71 */
+HD_DECL2(hd_pb_logmap, const void* p1, const void* p2, void* out, int64_t rows, int64_t dim, hd_curv c,
+         void* stream)
+/* the per-row loops of models/direction_diffusion.py:305-306,350-352 (logmap at the row's
+ * cluster centre) and :328-330 (expmap at it): base point = centres[labels[row]] */
+HD_DECL2(hd_pb_logmap_at, const void* centres, const int32_t* labels, int64_t n_centres, const void* x,
+         void* out, int64_t rows, int64_t dim, hd_curv c, void* stream)
+HD_DECL2(hd_pb_expmap_at, const void* centres, const int32_t* labels, int64_t n_centres, const void* u,
+         void* out, int64_t rows, int64_t dim, hd_curv c, void* stream)
+/* sqdist :25-31 -> out (rows,) */
+HD_DECL2(hd_pb_sqdist, const void* p1, const void* p2, void* out, int64_t rows, int64_t dim, hd_curv c,
+         void* stream)
+/* tail of mobius_matvec :93-102 after mx = x @ W^T (hd_gemm): needs |x| per row (hd_rownorm).
+ * flags bit0: follow with proj (HypLinear.forward, layers/hyp_layers.py:100-101);
+ * flags bit1: then logmap0, i.e. emit the tangent vector HypAgg consumes (:134). */
+HD_DECL2(hd_pb_matvec_epilogue, const void* mx, const void* xnorm, void* out, int64_t rows, int64_t dim,
+         hd_curv c, int flags, void* stream)
+/* HypAct.forward, layers/hyp_layers.py:170-173 */
+HD_DECL2(hd_pb_hyp_act, const void* x, void* out, int64_t rows, int64_t dim, hd_curv c_in, hd_curv c_out,
+         int act, void* stream)
+
+/* ---- Hyperboloid, manifolds/hyperboloid.py (column 0 = time coordinate) --------- */
+/* proj :43-52 */
+HD_DECL2(hd_hb_proj, const void* x, void* out, int64_t rows, int64_t dim, hd_curv c, void* stream)
+/* proj_tan0 :64-68 */
+HD_DECL2(hd_hb_proj_tan0, const void* u, void* out, int64_t rows, int64_t dim, hd_curv c, void* stream)
+/* expmap0 :90-101 (includes its trailing proj) */
+HD_DECL2(hd_hb_expmap0, const void* u, void* out, int64_t rows, int64_t dim, hd_curv c, void* stream)
+/* logmap0 :103-113 (arcosh in fp64, utils/math_utils.py:57-63) */
+HD_DECL2(hd_hb_logmap0, const void* x, void* out, int64_t rows, int64_t dim, hd_curv c, void* stream)
+/* proj(expmap0(proj_tan0(x))) -- input lift, models/encoders.py:115-119 */
+HD_DECL2(hd_hb_expmap0_proj, const void* u, void* out, int64_t rows, int64_t dim, hd_curv c, void* stream)
+/* sqdist :35-41 -> out (rows, 1) */
+HD_DECL2(hd_hb_sqdist, const void* x, const void* y, void* out, int64_t rows, int64_t dim, hd_curv c,
+         void* stream)
+/* tail of mobius_matvec :120-123 after mu = logmap0(x) @ W^T: expmap0; flags as above */
+HD_DECL2(hd_hb_linear_epilogue, const void* mu, void* out, int64_t rows, int64_t dim, hd_curv c, int flags,
+         void* stream)
+HD_DECL2(hd_hb_hyp_act, const void* x, void* out, int64_t rows, int64_t dim, hd_curv c_in, hd_curv c_out,
+         int act, void* stream)
+
+/* row L2 norms (unclamped), x.norm(dim=-1) of manifolds/poincare.py:95 -> out (rows,) */
+HD_DECL2(hd_rownorm, const void* x, void* out, int64_t rows, int64_t dim, void* stream)
+
+/* ---- HypAgg: tangent-space CSR SpMM, layers/hyp_layers.py:133-152 (use_att=0) --- */
+/* COO (int64 row/col, the layout utils/data_utils.py:125-133 produces) -> CSR with int32
+ * rowptr (n_rows+1) and col (nnz), entries kept in COO order inside a row.  flags[0]:
+ * bit0 = input not row-sorted (sort stably on the host and call again), bit1 = index
+ * out of range. */
+int hd_csr_from_coo(const int64_t* row, const int64_t* col_in, int64_t nnz, int64_t n_rows, int64_t n_cols,
+                    int32_t* rowptr, int32_t* col, int32_t* flags, void* stream);
+/* plain torch.spmm(adj, x) :150 */
+HD_DECL2(hd_spmm_csr, const int32_t* rowptr, const int32_t* col, const void* val, const void* x, void* out,
+         int64_t rows, int64_t dim, void* stream)
+/* proj(expmap0(spmm(adj, xt))) :150-151, xt = logmap0(x) already in the tangent space (:134);
+ * fuse_act != 0 appends HypAct.forward (:170-173) with (c_in, c_out, act) in the same pass */
+HD_DECL2(hd_pb_agg, const int32_t* rowptr, const int32_t* col, const void* val, const void* xt, void* out,
+         int64_t rows, int64_t dim, hd_curv c_in, hd_curv c_out, int act, int fuse_act, void* stream)
+HD_DECL2(hd_hb_agg, const int32_t* rowptr, const int32_t* col, const void* val, const void* xt, void* out,
+         int64_t rows, int64_t dim, hd_curv c_in, hd_curv c_out, int act, int fuse_act, void* stream)
+
+/* ---- dense contractions ---------------------------------------------------------- */
+/* C[M,N] = epi(A[M,K] @ W[N,K]^T + bias[N]) on the exact-f32 matrix cores.
+ * x @ W^T of manifolds/poincare.py:96 / hyperboloid.py:122; nn.Linear (+F.gelu) of
+ * models/direction_diffusion.py:56-69.  epi: 0 none, 1 exact-erf GELU, 2 resid + GELU
+ * (ddpm.py:20-22).  K, lda, ldw multiples of 4, A/W 16-byte aligned (pad with zeros). */
+int hd_gemm_f32(const void* A, const void* W, const void* bias, const void* resid, void* C, int64_t M,
+                int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int epi, void* stream);
+/* double-precision x @ W^T (+bias) for fp64 HypLinear */
+int hd_gemm_f64(const void* A, const void* W, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
+                int64_t lda, int64_t ldw, int64_t ldc, void* stream);
+
+/* ---- direction diffusion, models/direction_diffusion.py ---------------------------- */
+/* dtype codes: 0 = f32, 1 = f64 */
+/* q_sample :198-213.  noise is modified IN PLACE when restrict != 0 (tran_direction :154-163
+ * with signs = sign(direction) as an fp32 (n_centres, dim) table).  t int64 (rows,),
+ * sqrt_ac / sqrt_1mac = get_alphas2 tables (:173-184, fp64, length T).  out is fp64. */
+int hd_q_sample(const void* x0, int x_dtype, void* noise, int noise_dtype, const int64_t* t,
+                const int32_t* labels, const float* signs, int64_t n_centres, const double* sqrt_ac,
+                const double* sqrt_1mac, int64_t T, double* out, int64_t rows, int64_t dim, int restrict_,
+                double sqrt_c, double horizon, double prior, void* stream);
+/* tran_direction :154-163, in place: noise[i] *= signs[labels[i]] */
+int hd_tran_direction(void* noise, int noise_dtype, const int32_t* labels, const float* signs, int64_t n_centres,
+                      int64_t rows, int64_t dim, void* stream);
+/* everything of p_sample :272-291 after the denoiser call: predict_noise_from_start :230-236 on
+ * the unclamped x0, clamp_(-1,1) in place :266-267, q_sample(x0, t2, eps, restrict=True) :289.
+ * The four table values are looked up on the host for the scalar steps t and t2. */
+int hd_p_sample_update(const void* x_t, int x_dtype, float* x0, const int32_t* labels, const float* signs,
+                       int64_t n_centres, double sqrt_recip_t, double sqrt_recipm1_t, double sqrt_ac_t2,
+                       double sqrt_1mac_t2, int64_t t, int64_t t2, double* out, int64_t rows, int64_t dim,
+                       double sqrt_c, double horizon, double prior, void* stream);
+/* torch.cat((x.float(), t[:,None]), 1).float() :57-58 into a zero-padded (rows, ld_out) fp32
+ * buffer.  t_kind: 0 = int64 per row, 1 = f32 per row, 2 = one scalar (t_scalar). */
+int hd_mlp_pack_input(const void* x, int x_dtype, const void* t, int t_kind, double t_scalar, float* out,
+                      int64_t rows, int64_t dim, int64_t ld_out, void* stream);
+/* normalization / renormal :145-153: out3 = {sum, sum of squares, count} over all elements
+ * (fp64 accumulation, fixed reduction tree -> bit-reproducible); workspace holds
+ * hd_moments_workspace_doubles() doubles. */
+int64_t hd_moments_workspace_doubles(void);
+int hd_moments(const void* x, int dtype, int64_t count, double* workspace, double* out3, void* stream);
+/* inverse == 0: (x - mean) / std ; inverse != 0: x * std + mean ; unbiased std, from moments3 */
+int hd_standardize(const void* x, void* out, int dtype, int64_t count, const double* moments3, int inverse,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYPDIFF_H */

@@ -1,0 +1,345 @@
+"""GPU: the HIP path (through the C ABI) against the reference-captured golden vectors
+and against the oracle on seeded inputs.  Bar: 1e-5 relative (north_star) for fp32,
+tighter for fp64; CSR indexing bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close
+from oracle import adjacency, diffusion as odiff, golden_inputs as gi, layers as olayers
+from oracle import manifolds as om
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": torch.float32, "f64": torch.float64}
+
+
+def G(a, dtype=None):
+    t = torch.from_numpy(np.array(a, copy=True)).cuda()
+    return t if dtype is None else t.to(dtype)
+
+
+def H(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib_loaded():
+    from hypdiff_amd import _lib
+    assert _lib.load().hd_version() >= 100
+    assert torch.cuda.is_available()
+
+
+# ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("mname", ["PoincareBall", "Hyperboloid"])
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_manifold_golden(golden, mname, dt):
+    import hypdiff_amd.manifolds as hm
+    man = getattr(hm, mname)()
+    g = golden("manifold_" + mname)
+    tol = dict(rtol=1e-5, atol_scale=1e-6) if dt == "f32" else dict(rtol=1e-9, atol_scale=1e-10)
+    with torch.no_grad():
+        for c in gi.MANIFOLD_CS:
+            for d in gi.MANIFOLD_DIMS:
+                for s in gi.MANIFOLD_SCALES:
+                    k = f"{dt}/c{c}/d{d}/s{s:g}/"
+                    u, v, w, p, q = (G(g[k + x]) for x in "uvwpq")
+                    chk = lambda out, name, **kw: assert_close(H(out), g[k + name], what=k + name, **{**tol, **kw})
+                    chk(man.proj(u, c), "proj")
+                    chk(man.expmap0(u, c), "expmap0")
+                    chk(man.logmap0(p, c), "logmap0")
+                    chk(man.logmap0(p, torch.tensor([c]).cuda()), "logmap0_ctensor")
+                    chk(man.mobius_matvec(w, p, c), "mobius_matvec")
+                    chk(man.sqdist(p, q, c), "sqdist")
+                    chk(man.proj_tan0(u, c), "proj_tan0")
+                    chk(man.mobius_add(p, q, c), "mobius_add")
+                    if mname == "PoincareBall":
+                        chk(man.expmap(v, p, c), "expmap")
+                        chk(man.logmap(p, q, c), "logmap")
+
+
+@pytest.mark.parametrize("mname", ["PoincareBall", "Hyperboloid"])
+@pytest.mark.parametrize("d", [3, 20, 64, 128, 257, 512, 1024, 2708])
+def test_manifold_vs_oracle_sizes(mname, d):
+    """All register-tile configurations (G=4/16/64, scalar and 16-byte loads) and the
+    streaming path for rows beyond the tile (d=2708: identity features of config 4)."""
+    import hypdiff_amd.manifolds as hm
+    man = getattr(hm, mname)()
+    pre = "pb_" if mname == "PoincareBall" else "hb_"
+    rs = np.random.RandomState(d)
+    for n in (1, 37, 300):
+        for scale in (0.05, 2.0):
+            u = (rs.standard_normal((n, d)) * scale / np.sqrt(d)).astype(np.float32)
+            u[0] = 0
+            for c in (0.6, 1.0):
+                ut = torch.from_numpy(u)
+                with torch.no_grad():
+                    p = getattr(om, pre + "proj")(getattr(om, pre + "expmap0")(ut, c), c)
+                    assert_close(H(man.expmap0(G(u), c)), getattr(om, pre + "expmap0")(ut, c), what="expmap0")
+                    assert_close(H(man.proj(G(u), c)), getattr(om, pre + "proj")(ut, c), what="proj")
+                    assert_close(H(man.logmap0(p.cuda(), c)), getattr(om, pre + "logmap0")(p, c), what="logmap0")
+                    if d <= 1024:
+                        from hypdiff_amd import ops
+                        got = ops.hyp_act(man.abi, p.cuda(), c, 1.0, 1)
+                        assert_close(H(got), olayers.hyp_act(mname, p, c, 1.0), what="hyp_act")
+                        q = torch.roll(p, 1, 0)
+                        assert_close(H(man.sqdist(p.cuda(), q.cuda(), c)), getattr(om, pre + "sqdist")(p, q, c),
+                                     what="sqdist", atol_scale=2e-6)
+
+
+def test_empty_inputs():
+    import hypdiff_amd.manifolds as hm
+    for man in (hm.PoincareBall(), hm.Hyperboloid()):
+        x = torch.zeros(0, 16, device="cuda")
+        assert man.expmap0(x, 1.0).shape == (0, 16)
+        assert man.logmap0(x, 1.0).shape == (0, 16)
+        assert man.sqdist(x, x, 1.0).shape[0] == 0
+
+
+def test_cpu_tensor_is_refused():
+    import hypdiff_amd.manifolds as hm
+    with pytest.raises(RuntimeError):
+        hm.PoincareBall().expmap0(torch.zeros(2, 4), 1.0)
+
+
+# ---------------------------------------------------------------------------------
+GRAPHS = [("ba", 100), ("ego", 17), ("community", 12), ("citation", 300)]
+
+
+def _adj(g, k0, n):
+    idx, val = G(g[k0 + "coo_indices"]), G(g[k0 + "coo_values"])
+    return torch.sparse_coo_tensor(idx, val, (n, n), check_invariants=False)
+
+
+@pytest.mark.parametrize("kind,n", GRAPHS)
+def test_csr_bit_exact(golden, kind, n):
+    from hypdiff_amd import ops
+    g = golden("layers")
+    k0 = f"{kind}{n}/"
+    csr = ops.csr_of(_adj(g, k0, n))
+    rowptr, col, val = adjacency.coo_to_csr(g[k0 + "coo_indices"], g[k0 + "coo_values"], n)
+    assert csr.rowptr.dtype == torch.int32 and csr.col.dtype == torch.int32
+    assert np.array_equal(H(csr.rowptr), rowptr)
+    assert np.array_equal(H(csr.col), col)
+    assert np.array_equal(H(csr.val), val)
+
+
+def test_csr_unsorted_empty_rows_and_bounds():
+    from hypdiff_amd import ops
+    rs = np.random.RandomState(3)
+    n = 50
+    row = rs.randint(5, 40, size=400)
+    col = rs.randint(0, n, size=400)
+    val = rs.standard_normal(400).astype(np.float32)
+    csr = ops.csr_from_coo(G(np.vstack([row, col]).astype(np.int64)), G(val), (n, n))
+    rp, cc, vv = adjacency.coo_to_csr(np.vstack([row, col]), val, n)
+    assert np.array_equal(H(csr.rowptr), rp) and np.array_equal(H(csr.col), cc) and np.array_equal(H(csr.val), vv)
+    empty = ops.csr_from_coo(torch.zeros(2, 0, dtype=torch.int64, device="cuda"), torch.zeros(0, device="cuda"), (7, 7))
+    assert np.array_equal(H(empty.rowptr), np.zeros(8, dtype=np.int32))
+    with pytest.raises(IndexError):
+        ops.csr_from_coo(G(np.array([[0, 1], [0, 99]], dtype=np.int64)), G(np.ones(2, dtype=np.float32)), (5, 5))
+
+
+def test_spmm_power_law_vs_oracle():
+    from hypdiff_amd import ops
+    n, d = 3000, 256
+    adj = gi.synthetic_graph("ba", n)
+    idx, val, shape = adjacency.process_adj(adj)
+    rs = np.random.RandomState(0)
+    x = rs.standard_normal((n, d)).astype(np.float32)
+    csr = ops.csr_from_coo(G(idx), G(val), shape)
+    got = ops.spmm(csr, G(x))
+    want = olayers.spmm_coo(torch.from_numpy(idx), torch.from_numpy(val), shape, torch.from_numpy(x))
+    assert_close(H(got), want, what="spmm")
+    # linearity: A(ax + by) == a Ax + b Ay
+    y = rs.standard_normal((n, d)).astype(np.float32)
+    lhs = ops.spmm(csr, G(2 * x - 3 * y))
+    rhs = 2 * got - 3 * ops.spmm(csr, G(y))
+    assert_close(H(lhs), H(rhs), rtol=1e-4, atol_scale=1e-5, what="spmm linearity")
+
+
+@pytest.mark.parametrize("kind,n", GRAPHS)
+@pytest.mark.parametrize("mname,c", [("PoincareBall", 0.6), ("Hyperboloid", 1.0)])
+def test_layers_golden(golden, kind, n, mname, c):
+    import hypdiff_amd.manifolds as hm
+    from hypdiff_amd.layers import hyp_layers as L
+    import torch.nn.functional as F
+    g = golden("layers")
+    k0 = f"{kind}{n}/"
+    adj = _adj(g, k0, n)
+    man = getattr(hm, mname)()
+    for bias in (0, 1):
+        k = k0 + f"{mname}/bias{bias}/"
+        if k + "encode" not in g.files:
+            continue
+        dim = g[k + "W0"].shape[0]
+        feat = g[k + "W0"].shape[1]
+        ct = torch.tensor([c]).cuda()
+        layers = []
+        for i, (fi, fo) in enumerate([(feat, dim), (dim, dim)]):
+            lyr = L.HyperbolicGraphConvolution(man, fi, fo, ct, ct, 0.0, F.relu, bias, 0, 0).cuda().eval()
+            lyr.linear.load_state_dict({"weight": torch.from_numpy(g[k + f"W{i}"]), "bias": torch.from_numpy(g[k + f"b{i}"])})
+            layers.append(lyr)
+        with torch.no_grad():
+            h = G(g[k + "lift"])
+            for i, lyr in enumerate(layers):
+                hin = G(g[k + f"L{i-1}/act"]) if i else h
+                assert_close(H(lyr.linear(hin)), g[k + f"L{i}/linear"], what=k + f"L{i}/linear")
+                assert_close(H(lyr.agg(G(g[k + f"L{i}/linear"]), adj)), g[k + f"L{i}/agg"], what=k + f"L{i}/agg")
+                assert_close(H(lyr.hyp_act(G(g[k + f"L{i}/agg"]))), g[k + f"L{i}/act"], what=k + f"L{i}/act")
+                fused, _ = lyr((hin, adj))
+                assert_close(H(fused), g[k + f"L{i}/act"], rtol=2e-5, atol_scale=2e-6, what=k + f"L{i}/fused")
+
+
+@pytest.mark.parametrize("kind,n", GRAPHS)
+@pytest.mark.parametrize("mname,c", [("PoincareBall", 0.6), ("Hyperboloid", 1.0)])
+def test_hgcn_encode_golden(golden, kind, n, mname, c):
+    import types
+    from hypdiff_amd.models.encoders import HGCN
+    g = golden("layers")
+    k0 = f"{kind}{n}/"
+    k = k0 + f"{mname}/bias0/"
+    dim = g[k + "W0"].shape[0]
+    feat = g[k + "W0"].shape[1]
+    args = types.SimpleNamespace(manifold=mname, c=c, cuda=0, device="cuda:0", feat_dim=feat, dim=dim, num_layers=2,
+                                 act="relu", dropout=0.0, bias=0, use_att=0, local_agg=0)
+    enc = HGCN(torch.tensor([c]).cuda(), args).cuda().eval()
+    for i, lyr in enumerate(enc.layers):
+        lyr.linear.load_state_dict({"weight": torch.from_numpy(g[k + f"W{i}"]), "bias": torch.from_numpy(g[k + f"b{i}"])})
+    x = G(g[k0 + "features"])
+    if mname == "Hyperboloid":
+        x = torch.cat([torch.zeros_like(x[:, :1]), x], 1)       # models/base_models.py:79-81
+    with torch.no_grad():
+        out = enc.encode(x, _adj(g, k0, n))
+    assert_close(H(out), g[k + "encode"], rtol=3e-5, atol_scale=3e-6, what=k + "encode")
+
+
+# ---------------------------------------------------------------------------------
+def test_gemm_vs_fp64():
+    from hypdiff_amd import ops
+    rs = np.random.RandomState(1)
+    for (M, N, K) in [(1, 5, 8), (129, 700, 900), (300, 64, 516), (1000, 800, 65), (257, 130, 36)]:
+        a = rs.standard_normal((M, K)).astype(np.float32)
+        w = rs.standard_normal((N, K)).astype(np.float32)
+        # asymmetric, exactly representable check first (catches transposed fragment maps)
+        ai = rs.randint(-4, 5, size=(M, K)).astype(np.float32)
+        wi = rs.randint(-4, 5, size=(N, K)).astype(np.float32)
+        assert np.array_equal(H(ops.gemm(G(ai), G(wi))), ai @ wi.T)
+        b = rs.standard_normal(N).astype(np.float32)
+        ref = a.astype(np.float64) @ w.astype(np.float64).T + b
+        mag = np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64).T
+        got = H(ops.gemm(G(a), G(w), G(b)))
+        assert np.all(np.abs(got - ref) <= 2e-6 * mag + 1e-6), (M, N, K, np.abs(got - ref).max())
+        gl = H(ops.gemm(G(a), G(w), G(b), epi=1))
+        want = torch.nn.functional.gelu(torch.from_numpy(ref)).numpy()
+        assert np.all(np.abs(gl - want) <= 2e-6 * mag + 1e-6)
+        a64, w64 = a.astype(np.float64), w.astype(np.float64)
+        assert_close(H(ops.gemm(G(a64), G(w64))), a64 @ w64.T, rtol=1e-12, atol_scale=1e-13, what="gemm f64")
+
+
+def _diff(dim=16, T=200):
+    import types
+    from hypdiff_amd.models.direction_diffusion import diffusion
+    d = diffusion(types.SimpleNamespace(r=2.0, t=1.0), dim, num_timesteps=T).eval()
+    sd = {}
+    for i, (w, b) in enumerate(gi.mlp_params(dim), 1):
+        sd[f"fc{i}.weight"] = torch.from_numpy(w)
+        sd[f"fc{i}.bias"] = torch.from_numpy(b)
+    d.mlp.load_state_dict(sd)
+    return d
+
+
+def test_schedule_tables_golden(golden):
+    g = golden("diffusion")
+    for T in (200, 1000):
+        d = _diff(16, T)
+        for ours, theirs in (("alphas_cumprod", "alphas_cumprod"), ("sqrt_alphas_cumprod", "sqrt_alphas_cumprod"),
+                             ("minus_alphas_cumprod", "minus_alphas_cumprod"),
+                             ("sqrt_recip_alphas_cumprod", "sqrt_recip_alphas_cumprod"),
+                             ("sqrt_recipm1_alphas_cumprod", "sqrt_recipm1_alphas_cumprod")):
+            assert np.array_equal(H(getattr(d, ours)), g[f"T{T}/{theirs}"])
+
+
+def test_q_sample_golden(golden):
+    g = golden("diffusion")
+    d = _diff()
+    u0 = G(g["c/u0"])
+    labels = g["c/labels"]
+    t = G(g["c/t"])
+    with torch.no_grad():
+        direction = d.directions(u0)
+        assert np.array_equal(np.sign(H(torch.stack(direction))), np.sign(g["c/direction"]))
+        for tag, xdt, ndt in (("f64f64", torch.float64, torch.float64), ("f32f64", torch.float32, torch.float64),
+                              ("f32f32", torch.float32, torch.float32)):
+            x = G(g["c/x"], xdt)
+            for r in (0, 1):
+                nz = G(g["c/noise"], ndt)
+                out = d.q_sample(x, t, direction, nz, labels, u0, restrict=bool(r))
+                assert out.dtype == torch.float64
+                assert_close(H(out), g[f"q_sample/{tag}/restrict{r}/out"], rtol=1e-6, atol_scale=1e-7,
+                             what=f"q_sample {tag} {r}")
+                assert np.array_equal(H(nz), g[f"q_sample/{tag}/restrict{r}/noise_after"])
+
+
+def test_mlp_and_p_sample_golden(golden):
+    g = golden("diffusion")
+    d = _diff()
+    u0 = G(g["c/u0"])
+    labels = g["c/labels"]
+    t = G(g["c/t"])
+    params = [(torch.from_numpy(w), torch.from_numpy(b)) for w, b in gi.mlp_params(16)]
+    with torch.no_grad():
+        direction = d.directions(u0)
+        x = G(g["c/x"], torch.float64)
+        assert_close(H(d.mlp(x, t)), g["mlp/int_t"], what="mlp int t")
+        assert_close(H(d.mlp(x, t / 200)), g["mlp/frac_t"], what="mlp frac t")
+        for T, pre in ((200, ""), (1000, "T1000/")):
+            dd = d if T == 200 else _diff(16, 1000)
+            for tag, xdt in (("f32", torch.float32), ("f64", torch.float64)):
+                for step in ((150, 1, 0) if T == 200 else (999, 500, 0)):
+                    key = f"{pre}p_sample/{tag}/t{step}/" if T == 200 else f"{pre}p_sample/t{step}/"
+                    if key + "pred" not in g.files:
+                        continue
+                    img = torch.from_numpy(g["c/img"]).to(xdt)
+                    raw = float(odiff.mlp_denoiser(img, torch.full((24,), step), params).abs().max())
+                    pred, x0 = dd.p_sample(img.cuda(), None, 1, direction, labels, u0, step, None, True)
+                    assert pred.dtype == torch.float64 and x0.dtype == torch.float32
+                    assert_close(H(x0), g[key + "x_start"], what=key + "x0", scale=raw)
+                    assert_close(H(pred), g[key + "pred"], what=key + "pred",
+                                 scale=max(raw, float(np.abs(g[key + "pred"]).max())))
+
+
+def test_forward_loss_and_loop_golden(golden):
+    g = golden("diffusion")
+    d = _diff()
+    u0 = G(g["c/u0"])
+    labels = g["c/labels"]
+    t = G(g["c/t"])
+    with torch.no_grad():
+        for tag, xdt in (("f32", torch.float32), ("f64", torch.float64)):
+            x = G(g["c/x"], xdt)
+            loss = d(x, 1, labels, u0, restrict=True, graphset=True, t=t, noise=G(g["c/noise"], torch.float64))
+            assert_close(H(loss), g[f"forward/{tag}/loss"], what="loss " + tag)
+            assert_close(H(x), g[f"forward/{tag}/x_after"], what="x mutated " + tag)     # in-place side effect
+        x = G(g["c/x"], torch.float32)
+        ret = d.p_sample_loop(x, 1, labels, u0, graphset=True, img=G(g["c/img"]))
+        assert_close(H(x), g["p_sample_loop/f32/x_after"], what="loop x mutated")
+        # 200 chained fp32 denoiser evaluations compound rounding: looser end-point bar
+        assert_close(H(ret), g["p_sample_loop/f32/ret"], rtol=1e-3, atol_scale=1e-4, what="loop")
+
+
+def test_full_size_properties():
+    """Config-2-sized batch (sum N = 15 777, D = 512): properties that need no oracle run."""
+    import hypdiff_amd.manifolds as hm
+    n, dim = 15777, 512
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    u = torch.randn(n, dim, device="cuda", generator=gen) * 0.05
+    for man in (hm.PoincareBall(), hm.Hyperboloid()):
+        with torch.no_grad():
+            uu = man.proj_tan0(u, 1.0) if man.name == "Hyperboloid" else u
+            p = man.proj(man.expmap0(uu, 1.0), 1.0)
+            back = man.logmap0(p, 1.0)
+            assert_close(H(back), H(uu), rtol=1e-4, atol_scale=1e-5, what=man.name + " log0(exp0(u)) == u")
+            assert_close(H(man.proj(p, 1.0)), H(p), rtol=1e-6, atol_scale=1e-7, what="proj idempotent")
+            sd = man.sqdist(p, p, 1.0)
+            assert float(sd.abs().max()) < 1e-5
