@@ -142,9 +142,11 @@ class diffusion(nn.Module):
     # ---- direction handling ----------------------------------------------------------
     def _signs(self, direction):
         """(K, D) fp32 table of sign(direction[k]) (:159), cached per direction list."""
-        key = tuple((d.data_ptr(), d._version) for d in direction)
+        key = tuple((id(d), d._version) for d in direction)
         if self._sign_cache is None or self._sign_cache[0] != key:
-            self._sign_cache = (key, torch.sign(torch.stack(list(direction))).to(torch.float32).contiguous())
+            # the cache keeps the direction tensors alive, so their ids cannot be reused
+            self._sign_cache = (key, torch.sign(torch.stack(list(direction))).to(torch.float32).contiguous(),
+                                list(direction))
         return self._sign_cache[1]
 
     def directions(self, u0):

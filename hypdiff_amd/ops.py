@@ -5,6 +5,7 @@ enqueues HIP kernels of libhypdiff_hip.so on the current stream and returns with
 synchronising.  Inputs must live on the GPU; nothing here computes on the CPU.
 """
 import ctypes
+import weakref
 
 import numpy as np
 import torch
@@ -27,16 +28,18 @@ def curv(c):
     if isinstance(c, HdCurv):
         return c
     if torch.is_tensor(c):
-        key = (c.data_ptr(), c._version, c.dtype, c.device)
-        hit = _curv_cache.get(key)
-        if hit is None:
-            ch = c.detach().reshape(-1)[:1].cpu()
-            K = 1.0 / ch
-            hit = HdCurv(float(ch), float(ch ** 0.5), float(K), float(K ** 0.5))
-            if len(_curv_cache) > 256:
-                _curv_cache.clear()
-            _curv_cache[key] = hit
-        return hit
+        # keyed by object identity and guarded by a weak reference + version counter: a
+        # freed tensor's id / storage address can be reused by a different curvature
+        hit = _curv_cache.get(id(c))
+        if hit is not None and hit[0]() is c and hit[1] == c._version:
+            return hit[2]
+        ch = c.detach().reshape(-1)[:1].cpu()
+        K = 1.0 / ch
+        val = HdCurv(float(ch), float(ch ** 0.5), float(K), float(K ** 0.5))
+        if len(_curv_cache) > 256:
+            _curv_cache.clear()
+        _curv_cache[id(c)] = (weakref.ref(c), c._version, val)
+        return val
     c = float(c)
     return HdCurv(c, c ** 0.5, 1.0 / c, (1.0 / c) ** 0.5)
 
