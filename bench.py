@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py -- latent node-steps/sec (HGCN encode + DDPM step) on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic input:
+    HGCN.encode (Hyperboloid, c=1, 2 layers, dim 512) over the block-diagonal batch of a
+    SynEgo1000-shaped graph set (1197 graphs, sum N = 15 777 rows), followed by one
+    direction-diffusion p_sample step (mlp denoiser + fused update, T = 1000 tables)
+    over the (sum N, 512) latents.
+value = rows processed by all ranks / wall time (inputs resident in HBM before timing).
+
+    python bench.py --gpus N --steps K --warmup W
+For N > 1 launch one rank per GPU (torch.distributed.run); each rank owns its own
+graph-set shard of the same size (weak scaling, no data-path collective in the step).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix peak
+HBM_PEAK_GBS = 8000.0
+
+
+def build_workload(dim, T, seed, device):
+    from hypdiff_amd import ops, workloads
+    from hypdiff_amd.models.direction_diffusion import diffusion
+    from hypdiff_amd.models.encoders import HGCN
+    mats, sizes = workloads.ego_graph_set(seed=seed)
+    feat = 20
+    idx, val, shape, feats = workloads.batch_graph_set(mats, sizes, feat)
+    n = shape[0]
+    torch.manual_seed(seed)
+    args = types.SimpleNamespace(manifold="Hyperboloid", c=1.0, cuda=0, device=device, feat_dim=feat + 1, dim=dim,
+                                 num_layers=2, act="relu", dropout=0.0, bias=0, use_att=0, local_agg=0)
+    enc = HGCN(torch.tensor([1.0], device=device), args).to(device).eval()
+    diff = diffusion(types.SimpleNamespace(r=2.0, t=1.0), dim, num_timesteps=T).eval()
+    adj = torch.sparse_coo_tensor(torch.from_numpy(idx).to(device), torch.from_numpy(val).to(device), shape,
+                                  check_invariants=False)
+    x = torch.from_numpy(feats).to(device)
+    x = torch.cat([torch.zeros_like(x[:, :1]), x], dim=1).contiguous()     # base_models.py:79-81
+    rs = np.random.RandomState(seed)
+    labels = rs.randint(0, 3, size=n).astype(np.int64)
+    u0 = torch.from_numpy((rs.standard_normal((3, dim)) * 0.05).astype(np.float32)).to(device)
+    img = torch.from_numpy(rs.standard_normal((n, dim))).to(device)        # fp64 state, as after step 1
+    with torch.no_grad():
+        direction = diff.directions(u0)
+        ops.csr_of(adj)
+    host = dict(idx=idx, val=val, shape=shape, x=x.cpu(), labels=labels, u0=u0.cpu(), img=img.cpu())
+    return dict(enc=enc, diff=diff, adj=adj, x=x, labels=labels, u0=u0, img=img, direction=direction, n=n,
+                nnz=idx.shape[1], host=host, feat=feat + 1)
+
+
+def one_step(w, t):
+    h = w["enc"].encode(w["x"], w["adj"])
+    pred, x0 = w["diff"].p_sample(w["img"], None, 1, w["direction"], w["labels"], w["u0"], t, None, True)
+    return h, pred
+
+
+def cpu_baseline(w, dim, T, budget_s=20.0):
+    """The oracle (CPU port of the reference path) on the same workload, host cores."""
+    from oracle import diffusion as odiff, layers as olayers
+    enc, diff, host = w["enc"], w["diff"], w["host"]
+    Ws = [l.linear.weight.detach().cpu() for l in enc.layers]
+    params = [(getattr(diff.mlp, f"fc{i}").weight.detach().cpu(), getattr(diff.mlp, f"fc{i}").bias.detach().cpu())
+              for i in range(1, 6)]
+    adj = (torch.from_numpy(host["idx"]), torch.from_numpy(host["val"]), host["shape"])
+    tables = odiff.schedule(T)
+    signs = odiff.sign_table(host["u0"])
+    cores = torch.get_num_threads()
+
+    def step(t):
+        olayers.hgcn_encode("Hyperboloid", host["x"], adj, Ws, [1.0, 1.0, 1.0], prepend_time=False)
+        odiff.p_sample(host["img"], t, signs, host["labels"], tables, params)
+
+    with torch.no_grad():
+        step(T - 1)
+        n, t0 = 0, time.perf_counter()
+        while n < 30 and (time.perf_counter() - t0) < budget_s:
+            step(T - 2 - n)
+            n += 1
+        dt = time.perf_counter() - t0
+    return dict(value=w["n"] * n / dt, unit="node-steps/s", cores=cores, kind="port",
+                sample=f"{n} full steps of the same workload ({w['n']} rows) with the torch-CPU oracle, "
+                       f"{cores} threads, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dim", type=int, default=512)
+    ap.add_argument("--timesteps", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    device = f"cuda:{local_rank if world > 1 else 0}"
+
+    from hypdiff_amd import ops
+    T = a.timesteps
+    w = build_workload(a.dim, T, 1432 + rank, device)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for i in range(a.warmup):
+            one_step(w, T - 1 - (i % T))
+        barrier()
+        ops.GEMM_EVENTS = []
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            one_step(w, T - 1 - (i % T))
+        barrier()
+        elapsed = time.perf_counter() - t0
+        events, ops.GEMM_EVENTS = ops.GEMM_EVENTS, None
+
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # dominant kernel: the fp32 MFMA GEMM (denoiser + HypLinear); live HIP-event timing
+    flops = sum(e[2] for e in events)
+    gemm_ms = sum(e[0].elapsed_time(e[1]) for e in events)
+    achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    rows_total = w["n"] * a.steps * world
+    out = {
+        "metric": "latent node-steps/sec (HGCN encode + DDPM step)",
+        "value": rows_total / elapsed, "unit": "node-steps/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: SynEgo1000-shaped graph set (1197 ego graphs, sum N=%d, nnz=%d), "
+                               "Hyperboloid c=1 HGCN encode (21->%d->%d) + direction-diffusion p_sample "
+                               "(mlp denoiser, T=%d tables)" % (w["n"], w["nnz"], a.dim, a.dim, T),
+                   "rows_per_gpu": w["n"], "dim": a.dim, "timesteps": T, "parallelism": "graph-set shards x%d" % world},
+        "roofline": {"bound": "mfma", "kernel": "gemm_f32_mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                     "launches": len(events), "gemm_ms_per_step": gemm_ms / a.steps},
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(w, a.dim, T)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,7 @@ from ._lib import HdCurv
 ACT_CODES = {"identity": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "elu": 4, "leaky_relu": 5}
 
 _curv_cache = {}
+GEMM_EVENTS = None      # set to a list by bench.py to time every hd_gemm_f32 launch
 
 
 def curv(c):
@@ -168,8 +169,15 @@ def gemm(a, w, bias=None, epi=0, resid=None, out=None):
         a, w = _pad_k(a, kp), _pad_k(w, kp)
     a = a if a.stride(1) == 1 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 else a.contiguous()
     w = w if w.stride(1) == 1 and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0 else w.contiguous()
+    ev = GEMM_EVENTS
+    if ev is not None:          # bench.py: live HIP-event timing of the dominant kernel
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.call("hd_gemm_f32", _p(a), _p(w), _p(bias), _p(resid), _p(out), M, N, a.shape[1], a.stride(0),
               w.stride(0), out.stride(0), epi, _stream())
+    if ev is not None:
+        e1.record()
+        ev.append((e0, e1, 2.0 * M * N * K))
     return out
 
 

@@ -1,0 +1,61 @@
+"""Synthetic graph-set workloads shaped like the reference's datasets (host-side numpy).
+
+The shipped pickles are never unpickled; graph sets are regenerated with the same
+statistics: SynEgo1000 = 1197 ego graphs, 4-20 nodes,
+sum N = 15 777, sum E = 16 608.  Adjacency preprocessing restates
+utils/data_utils.py:103-133 (`normalize(A + I)` = D^-1 (A+I), COO, fp32 values) and
+GraphDataset's identity features (diff.py:38-39), batched block-diagonally so the whole
+set is one CSR.
+"""
+import numpy as np
+import scipy.sparse as sp
+
+
+def ego_graph_set(n_graphs=1197, total_nodes=15777, total_edges=16608, n_min=4, n_max=20, seed=1432):
+    rs = np.random.RandomState(seed)
+    sizes = np.clip(np.rint(rs.normal(total_nodes / n_graphs, 4.0, n_graphs)), n_min, n_max).astype(np.int64)
+    while sizes.sum() != total_nodes:                       # nudge to the exact node count
+        i = rs.randint(n_graphs)
+        step = 1 if sizes.sum() < total_nodes else -1
+        if n_min <= sizes[i] + step <= n_max:
+            sizes[i] += step
+    extra = max(0, total_edges - int((sizes - 1).sum()))    # chords beyond the ego star
+    chord_p = extra / max(1, int((sizes - 1).sum()))
+    mats = []
+    for n in sizes:
+        r, c = [], []
+        for i in range(1, n):
+            r += [0, i]; c += [i, 0]
+            if rs.rand() < chord_p and n > 2:
+                j = 1 + rs.randint(n - 1)
+                if j != i:
+                    r += [i, j]; c += [j, i]
+        a = sp.csr_matrix((np.ones(len(r)), (r, c)), shape=(n, n))
+        a.data[:] = 1.0
+        mats.append(a)
+    return mats, sizes
+
+
+def normalize_adj(adj):
+    """utils/data_utils.py:109-122: D^-1 (A + I) in fp64, zero for empty rows."""
+    mx = adj + sp.eye(adj.shape[0])
+    rowsum = np.asarray(mx.sum(1), dtype=np.float64).reshape(-1)
+    with np.errstate(divide="ignore"):
+        r_inv = np.power(rowsum, -1.0)
+    r_inv[np.isinf(r_inv)] = 0.0
+    return sp.diags(r_inv).dot(mx)
+
+
+def batch_graph_set(mats, sizes, feat_dim):
+    """One block-diagonal normalised COO (int64 indices, fp32 values, row-sorted) and the
+    per-node identity features of width feat_dim (node i of a graph -> e_i)."""
+    big = sp.block_diag([normalize_adj(a) for a in mats], format="csr").tocoo()
+    idx = np.vstack((big.row, big.col)).astype(np.int64)
+    val = big.data.astype(np.float32)
+    n = int(sizes.sum())
+    feats = np.zeros((n, feat_dim), dtype=np.float32)
+    off = 0
+    for s in sizes:
+        feats[np.arange(off, off + s), np.arange(s)] = 1.0
+        off += s
+    return idx, val, (n, n), feats
