@@ -31,13 +31,25 @@ template <int BNT>
 __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A, const float* __restrict__ W,
                                                      const float* __restrict__ bias,
                                                      const float* __restrict__ resid, float* __restrict__ C,
-                                                     int M, int N, int K, int lda, int ldw, int ldc, int epi) {
+                                                     int M, int N, int K, int lda, int ldw, int ldc, int epi,
+                                                     int tiles_m, int tiles_n) {
     constexpr int NT = BNT / 64;               // 32-col MFMA tiles per wavefront along N: 2 (BN=128) or 1 (BN=64)
     __shared__ __attribute__((aligned(16))) float sA[BM * PITCH];
     __shared__ __attribute__((aligned(16))) float sW[BNT * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BNT;
+    // Tile order.  The hardware deals consecutive workgroup ids round-robin over the 8
+    // XCDs (private L2 each).  Give every XCD a contiguous run of tile ids (bijective
+    // remap) and walk N fastest inside it, so the workgroups that share one 128-row A
+    // panel run back to back on ONE L2 and the (small) weight matrix stays L2-resident;
+    // A then leaves HBM / Infinity Cache once instead of once per N tile (+7 % measured).
+    int tile = blockIdx.x;
+    {
+        const int nwg = tiles_m * tiles_n, q = nwg >> 3, r = nwg & 7, xcd = tile & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (tile >> 3);
+    }
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BNT;
 
     // staging map: 8 threads cover one row's 128 B; 32 rows per pass
     const int srow = tid >> 3, skq = (tid & 7) * 4;
@@ -189,16 +201,17 @@ extern "C" int hd_gemm_f32(const void* A, const void* W, const void* bias, const
     // narrow block tile when it wastes fewer padded columns or is needed to fill 256 CUs
     const int64_t t128 = ((N + 127) / 128) * ((M + 127) / 128);
     const bool narrow = ((N + 63) / 64) * 64 < ((N + 127) / 128) * 128 || t128 < 256;
+    const int tiles_m = (int)((M + BM - 1) / BM);
     if (narrow) {
-        const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + 63) / 64));
-        gemm_f32_mfma<64><<<grid, blk, 0, (hipStream_t)st>>>((const float*)A, (const float*)W, (const float*)bias,
-                                                           (const float*)resid, (float*)C, (int)M, (int)N, (int)K,
-                                                           (int)lda, (int)ldw, (int)ldc, epi);
+        const int tiles_n = (int)((N + 63) / 64);
+        gemm_f32_mfma<64><<<dim3((unsigned)(tiles_m * tiles_n)), blk, 0, (hipStream_t)st>>>(
+            (const float*)A, (const float*)W, (const float*)bias, (const float*)resid, (float*)C, (int)M, (int)N,
+            (int)K, (int)lda, (int)ldw, (int)ldc, epi, tiles_m, tiles_n);
     } else {
-        const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + 127) / 128));
-        gemm_f32_mfma<128><<<grid, blk, 0, (hipStream_t)st>>>((const float*)A, (const float*)W, (const float*)bias,
-                                                            (const float*)resid, (float*)C, (int)M, (int)N, (int)K,
-                                                            (int)lda, (int)ldw, (int)ldc, epi);
+        const int tiles_n = (int)((N + 127) / 128);
+        gemm_f32_mfma<128><<<dim3((unsigned)(tiles_m * tiles_n)), blk, 0, (hipStream_t)st>>>(
+            (const float*)A, (const float*)W, (const float*)bias, (const float*)resid, (float*)C, (int)M, (int)N,
+            (int)K, (int)lda, (int)ldw, (int)ldc, epi, tiles_m, tiles_n);
     }
     return check_launch("hd_gemm_f32");
 }

@@ -1,0 +1,9 @@
+import sys, torch
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hypdiff_amd import ops
+M, N, K = (int(v) for v in sys.argv[1:4])
+torch.manual_seed(0)
+a = torch.randn(M, K, device='cuda'); w = torch.randn(N, K, device='cuda'); b = torch.randn(N, device='cuda')
+out = torch.empty(M, N, device='cuda')
+for _ in range(6): ops.gemm(a, w, b, epi=1, out=out)
+torch.cuda.synchronize()

@@ -1,0 +1,90 @@
+"""CPU, world_size = 2 over gloo: the multi-rank host logic of hypdiff_amd/dist.py against
+the single-process result (the reference has no multi-GPU behaviour to compare with)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import adjacency, diffusion as odiff, golden_inputs as gi, layers as olayers
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hypdiff_amd import dist as hdist
+    torch.manual_seed(0)
+    res = {}
+    # (1) sharded normalization == global normalization
+    x = torch.randn(101, 16, dtype=torch.float64)
+    lo, hi = hdist.shard_range(101, rank, world)
+    xs = x[lo:hi]
+    m = torch.tensor([xs.sum().item(), (xs * xs).sum().item(), float(xs.numel())], dtype=torch.float64)
+    hdist.allreduce_moments(m)
+    mean = m[0] / m[2]
+    sd = torch.sqrt((m[1] - m[0] * m[0] / m[2]) / (m[2] - 1))
+    res["norm"] = torch.allclose((xs - mean) / sd, odiff.normalization(x)[lo:hi], rtol=1e-12, atol=1e-12)
+    # (2) flat gradient bucket: mean over ranks of per-shard gradients == full-batch gradient
+    lin = torch.nn.Linear(8, 4)
+    torch.manual_seed(1)
+    for p in lin.parameters():
+        torch.nn.init.normal_(p)
+    data = torch.randn(40, 8)
+    bucket = hdist.GradBucket(lin.parameters())
+    lo, hi = hdist.shard_range(40, rank, world)
+    lin(data[lo:hi]).pow(2).mean().backward()
+    bucket.allreduce_mean_()
+    ref = torch.nn.Linear(8, 4)
+    ref.load_state_dict(lin.state_dict())
+    ref(data).pow(2).mean().backward()
+    res["grad"] = all(torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6)
+                      for a, b in zip(lin.parameters(), ref.parameters()))
+    # (3) row-sharded aggregation with tangent all-gather == full SpMM, bit for bit
+    n, d = 203, 12
+    adj = gi.synthetic_graph("ba", n)
+    idx, val, shape = adjacency.process_adj(adj)
+    xt = torch.from_numpy(np.random.RandomState(5).standard_normal((n, d)).astype(np.float32))
+    full = olayers.spmm_coo(torch.from_numpy(idx), torch.from_numpy(val), shape, xt)
+    sh = hdist.RowShardedAdj(idx, val, shape, rank, world)
+    spmm = lambda i, v, s, xx: olayers.spmm_coo(torch.from_numpy(i), torch.from_numpy(v), s, xx)
+    out = sh.aggregate(xt[sh.lo:sh.hi], spmm)
+    res["agg"] = torch.equal(out, full[sh.lo:sh.hi])
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, res in got:
+        assert all(res.values()), (rank, res)
+
+
+def test_shard_range_covers():
+    from hypdiff_amd.dist import shard_range
+    for n in (0, 1, 7, 1197):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
