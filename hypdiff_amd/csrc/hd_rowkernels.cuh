@@ -159,7 +159,9 @@ __global__ __launch_bounds__(kBlock) void row_stream(const T* __restrict__ in, T
                 t0 = hd_sqrt(clamp_min((T)cv.K + nrm * nrm, (T)Lim<T>::hb_eps)); set_t0 = true; break;
             case S_HB_EXPMAP0: {
                 const T theta = n1 / sK;
-                f = sK * sinh15(theta) / n1;
+                T shv, chv;
+                sinhcosh15(theta, shv, chv);
+                f = sK * shv / n1;
                 const T n2 = f * nrm;
                 t0 = hd_sqrt(clamp_min((T)cv.K + n2 * n2, (T)Lim<T>::hb_eps)); set_t0 = true;
             } break;

@@ -1,0 +1,229 @@
+// HypAgg as a tangent-space CSR SpMM with the manifold tail fused in.
+//
+//   support[i] = sum_k val[k] * xt[col[k]]   (k over row i of the CSR, in stored order)
+//   out[i]     = epilogue(support[i])
+//
+// spmm_rows: one group of G lanes owns one output row and keeps its accumulator in
+// registers (lanes across features, neighbours visited in CSR order, which is the COO
+// order torch.spmm walks -- layers/hyp_layers.py:150).  The rows of a block are
+// consecutive, so their (col,val) entries form ONE contiguous CSR segment: the block
+// stages that segment into LDS with coalesced loads and every group reads its neighbour
+// list from LDS (same-address broadcast inside a group).  Neighbour rows are gathered
+// with 16-byte loads, eight in flight per lane (predicated at the row's end).
+//
+// spmm_long: power-law hubs.  A row with more than kLongRow neighbours would keep one
+// wavefront busy for milliseconds, so such rows are skipped by spmm_rows and handled by
+// one 512-thread workgroup each: its 8 wavefronts take 8 contiguous slices of the
+// neighbour list, and the 8 partial rows are added in slice order through LDS (fixed
+// shape -> bit-reproducible; differs from the strictly sequential sum by rounding only).
+//
+// The epilogue (expmap0 -> proj [-> HypAct]) runs on the register row, so the aggregate
+// costs one write of (N,d) and no intermediate (N,d) passes.
+#pragma once
+#include "hd_rowkernels.cuh"
+#include "../../include/hypdiff.h"
+
+namespace hd {
+
+constexpr int kStage = 2048;     // CSR entries staged per block iteration (16 KiB of LDS)
+constexpr int kLongRow = 512;    // rows with more neighbours go to spmm_long
+constexpr int kDepth = 8;        // neighbour rows in flight per lane
+
+enum Epi { E_NONE = 0, E_AGG = 1, E_AGG_ACT = 2 };
+
+template <class M, typename T, class TL>
+__device__ __forceinline__ void agg_epilogue(TL& acc, int epi, const Curv& cin, const Curv& cout, int act) {
+    if (epi >= E_AGG) {                    // layers/hyp_layers.py:151
+        M::expmap0(acc, cin);
+        M::proj(acc, cin);
+    }
+    if (epi == E_AGG_ACT) hyp_act<M, T>(acc, cin, cout, act);   // :170-173
+}
+
+// acc += sum over entries [k0, k1) read through (cols, vals) with index offset `off`
+template <typename T, class TL, class CI, class VI>
+__device__ __forceinline__ void gather_accumulate(TL& acc, const T* __restrict__ x, int d, int k0, int k1,
+                                                  const CI& cols, const VI& vals) {
+    for (; k0 < k1; k0 += kDepth) {
+        TL t[kDepth];
+        T w[kDepth];
+#pragma unroll
+        for (int u = 0; u < kDepth; ++u) {
+            t[u].init(d);
+            if (k0 + u < k1) {
+                t[u].load(x + (int64_t)cols(k0 + u) * d);
+                w[u] = vals(k0 + u);
+            } else {
+                t[u].zero();
+                w[u] = T(0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kDepth; ++u)
+#pragma unroll
+            for (int i = 0; i < TL::kRegs; ++i) acc.v[i] += w[u] * t[u].v[i];
+    }
+}
+
+template <class M, typename T, int G, int VEC, int REGS>
+__global__ __launch_bounds__(kBlock) void spmm_rows(const int32_t* __restrict__ rowptr,
+                                                    const int32_t* __restrict__ col,
+                                                    const T* __restrict__ val, const T* __restrict__ x,
+                                                    T* __restrict__ out, int64_t n, int d, int epi, Curv cin,
+                                                    Curv cout, int act, int skip_long) {
+    constexpr int RPB = kBlock / G;
+    __shared__ int32_t s_col[kStage];
+    __shared__ T s_val[kStage];
+    using TL = Tile<T, G, VEC, REGS>;
+    TL acc;
+    acc.init(d);
+    const int64_t nblk = (n + RPB - 1) / RPB;
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int64_t r0 = blk * RPB;
+        const int64_t r1 = r0 + RPB < n ? r0 + RPB : n;
+        const int64_t row = r0 + threadIdx.x / G;
+        bool valid = row < n;
+        int rs = 0, re = 0;
+        if (valid) { rs = rowptr[row]; re = rowptr[row + 1]; }
+        if (skip_long && re - rs > kLongRow) { valid = false; re = rs; }
+        const int seg0 = rowptr[r0], seg1 = rowptr[r1];
+        acc.zero();
+        if (seg1 - seg0 <= kStage) {
+            // common case: the whole segment of the block's rows fits one LDS stage
+            __syncthreads();
+            for (int i = threadIdx.x; i < seg1 - seg0; i += kBlock) {
+                s_col[i] = col[seg0 + i];
+                s_val[i] = val[seg0 + i];
+            }
+            __syncthreads();
+            gather_accumulate<T>(acc, x, d, rs, re, [&](int k) { return s_col[k - seg0]; },
+                                 [&](int k) { return s_val[k - seg0]; });
+        } else {
+            // a long (unsplit) row in this block: read the lists straight from global memory
+            gather_accumulate<T>(acc, x, d, rs, re, [&](int k) { return col[k]; }, [&](int k) { return val[k]; });
+        }
+        if (valid) {
+            agg_epilogue<M, T>(acc, epi, cin, cout, act);
+            acc.store(out + row * d);
+        }
+    }
+}
+
+constexpr int kLongWaves = 8;
+
+// one workgroup of kLongWaves wavefronts per long row (G = 64 lanes across features)
+template <class M, typename T, int VEC, int REGS>
+__global__ __launch_bounds__(kLongWaves * 64) void spmm_long(const int32_t* __restrict__ long_rows,
+                                                             const int32_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ col,
+                                                             const T* __restrict__ val, const T* __restrict__ x,
+                                                             T* __restrict__ out, int d, int epi, Curv cin,
+                                                             Curv cout, int act) {
+    using TL = Tile<T, 64, VEC, REGS>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* part = reinterpret_cast<T*>(smem);                 // [kLongWaves][d]
+    const int row = long_rows[blockIdx.x];
+    const int rs = rowptr[row], re = rowptr[row + 1];
+    const int wave = threadIdx.x >> 6;
+    const int len = re - rs, per = (len + kLongWaves - 1) / kLongWaves;
+    int k0 = rs + wave * per, k1 = k0 + per;
+    k0 = k0 < re ? k0 : re;
+    k1 = k1 < re ? k1 : re;
+    TL acc;
+    acc.init(d);
+    acc.zero();
+    gather_accumulate<T>(acc, x, d, k0, k1, [&](int k) { return col[k]; }, [&](int k) { return val[k]; });
+    acc.store(part + (size_t)wave * d);
+    __syncthreads();
+    if (wave == 0) {
+        TL tmp;
+        tmp.init(d);
+        for (int w = 1; w < kLongWaves; ++w) {
+            tmp.load(part + (size_t)w * d);
+#pragma unroll
+            for (int i = 0; i < TL::kRegs; ++i) acc.v[i] += tmp.v[i];
+        }
+        agg_epilogue<M, T>(acc, epi, cin, cout, act);
+        acc.store(out + (int64_t)row * d);
+    }
+}
+
+template <class M, typename T>
+int launch_spmm(const char* name, const int32_t* rowptr, const int32_t* col, const void* val, const void* x,
+                void* out, int64_t n, int64_t d, int epi, hd_curv ci, hd_curv co, int act,
+                const int32_t* long_rows, int64_t n_long, void* st) {
+    HD_REQUIRE(n >= 0 && d >= 1, "%s: bad shape rows=%lld dim=%lld", name, (long long)n, (long long)d);
+    if (n == 0) return HD_OK;
+    HD_REQUIRE(rowptr && col && val && x && out, "%s: null pointer", name);
+    HD_REQUIRE(x != out, "%s: out must not alias x (rows are gathered)", name);
+    HD_REQUIRE(n_long >= 0 && (n_long == 0 || long_rows), "%s: long-row list missing", name);
+    RowCfg c = pick_cfg<T>(d, is_aligned16(x) && is_aligned16(out));
+    HD_REQUIRE(c.ok, "%s: dim=%lld exceeds the register-tile limit", name, (long long)d);
+    const Curv cin{ci.c, ci.sqrt_c, ci.K, ci.sqrt_K}, cout{co.c, co.sqrt_c, co.K, co.sqrt_K};
+    const int ch = (int)((d + (int64_t)c.g * c.vec - 1) / ((int64_t)c.g * c.vec));
+    const int need = ch * c.vec;                       // registers the row needs per lane
+    hipStream_t s = (hipStream_t)st;
+    int rc = dispatch_cfg<T>(c, [&](auto g, auto v) {
+        constexpr int G = decltype(g)::value, V = decltype(v)::value;
+        constexpr int R0 = V < 4 ? 4 : V;              // smallest specialisation
+        if (sizeof(T) == 4 && need <= R0)
+            spmm_rows<M, T, G, V, R0><<<grid_for_rows(n, G), kBlock, 0, s>>>(
+                rowptr, col, (const T*)val, (const T*)x, (T*)out, n, (int)d, epi, cin, cout, act, n_long > 0);
+        else if (sizeof(T) == 4 && need <= 8)
+            spmm_rows<M, T, G, V, 8><<<grid_for_rows(n, G), kBlock, 0, s>>>(
+                rowptr, col, (const T*)val, (const T*)x, (T*)out, n, (int)d, epi, cin, cout, act, n_long > 0);
+        else
+            spmm_rows<M, T, G, V, kRegs><<<grid_for_rows(n, G), kBlock, 0, s>>>(
+                rowptr, col, (const T*)val, (const T*)x, (T*)out, n, (int)d, epi, cin, cout, act, n_long > 0);
+        return check_launch(name);
+    });
+    if (rc || n_long == 0) return rc;
+    // long rows: G = 64 always; scalar loads unless 16-byte rows
+    const int V = VecOf<T>::N;
+    const bool vec = is_aligned16(x) && is_aligned16(out) && d % V == 0;
+    const int64_t lanes = vec ? d / V : d;
+    HD_REQUIRE(lanes <= 64LL * (kRegs / (vec ? V : 1)), "%s: dim too large for the long-row kernel", name);
+    const size_t lds = (size_t)kLongWaves * d * sizeof(T);
+    HD_REQUIRE(lds <= 64 * 1024, "%s: dim too large for the long-row LDS reduce", name);
+    const int need64 = (int)((lanes + 63) / 64) * (vec ? V : 1);
+#define HD_LONG(VV, RR)                                                                                   \
+    spmm_long<M, T, VV, RR><<<(unsigned)n_long, kLongWaves * 64, lds, s>>>(                               \
+        long_rows, rowptr, col, (const T*)val, (const T*)x, (T*)out, (int)d, epi, cin, cout, act)
+    if (vec) {
+        if (sizeof(T) == 4 && need64 <= 4) HD_LONG(VecOf<T>::N, 4);
+        else if (sizeof(T) == 4 && need64 <= 8) HD_LONG(VecOf<T>::N, 8);
+        else HD_LONG(VecOf<T>::N, kRegs);
+    } else {
+        if (sizeof(T) == 4 && need64 <= 4) HD_LONG(1, 4);
+        else HD_LONG(1, kRegs);
+    }
+#undef HD_LONG
+    return check_launch(name);
+}
+
+}  // namespace hd
+
+#define HD_SPMM(T, sfx)                                                                                    \
+    extern "C" int hd_spmm_csr_##sfx(const int32_t* rowptr, const int32_t* col, const void* val,          \
+                                     const void* x, void* out, int64_t n, int64_t d,                       \
+                                     const int32_t* long_rows, int64_t n_long, void* st) {                 \
+        hd_curv one{1, 1, 1, 1};                                                                           \
+        return hd::launch_spmm<hd::PB<T>, T>("hd_spmm_csr_" #sfx, rowptr, col, val, x, out, n, d, hd::E_NONE, one, \
+                                             one, 0, long_rows, n_long, st);                               \
+    }                                                                                                      \
+    extern "C" int hd_pb_agg_##sfx(const int32_t* rowptr, const int32_t* col, const void* val,            \
+                                   const void* xt, void* out, int64_t n, int64_t d, hd_curv c_in,          \
+                                   hd_curv c_out, int act, int fuse_act, const int32_t* long_rows,         \
+                                   int64_t n_long, void* st) {                                             \
+        return hd::launch_spmm<hd::PB<T>, T>("hd_pb_agg_" #sfx, rowptr, col, val, xt, out, n, d,          \
+                                             fuse_act ? hd::E_AGG_ACT : hd::E_AGG, c_in, c_out, act,       \
+                                             long_rows, n_long, st);                                       \
+    }                                                                                                      \
+    extern "C" int hd_hb_agg_##sfx(const int32_t* rowptr, const int32_t* col, const void* val,            \
+                                   const void* xt, void* out, int64_t n, int64_t d, hd_curv c_in,          \
+                                   hd_curv c_out, int act, int fuse_act, const int32_t* long_rows,         \
+                                   int64_t n_long, void* st) {                                             \
+        return hd::launch_spmm<hd::HB<T>, T>("hd_hb_agg_" #sfx, rowptr, col, val, xt, out, n, d,          \
+                                             fuse_act ? hd::E_AGG_ACT : hd::E_AGG, c_in, c_out, act,       \
+                                             long_rows, n_long, st);                                       \
+    }

@@ -185,8 +185,15 @@ def gemm(a, w, bias=None, epi=0, resid=None, out=None):
 class CSR:
     """Device CSR (int32 rowptr/col, values in the COO's dtype and entry order)."""
 
+    LONG_ROW = 512          # kLongRow of csrc/hd_spmm.cuh
+
     def __init__(self, rowptr, col, val, shape):
         self.rowptr, self.col, self.val, self.shape = rowptr, col, val, shape
+        # rows with more than LONG_ROW entries (power-law hubs) get a workgroup each;
+        # found once per adjacency (one small read-back), empty for the graph-set configs
+        deg = rowptr[1:] - rowptr[:-1]
+        self.long_rows = (deg > self.LONG_ROW).nonzero().flatten().to(torch.int32).contiguous()
+        self.n_long = int(self.long_rows.numel())
 
     def values(self, dtype):
         return self.val if self.val.dtype == dtype else self.val.to(dtype)
@@ -240,7 +247,7 @@ def spmm(csr, x):
     x2 = x.contiguous()
     out = torch.empty(csr.shape[0], x2.shape[1], dtype=x2.dtype, device=x2.device)
     _lib.call("hd_spmm_csr" + _sfx(x2), _p(csr.rowptr), _p(csr.col), _p(csr.values(x2.dtype)), _p(x2), _p(out),
-              csr.shape[0], x2.shape[1], _stream())
+              csr.shape[0], x2.shape[1], _p(csr.long_rows) if csr.n_long else None, csr.n_long, _stream())
     return out
 
 
@@ -254,7 +261,8 @@ def agg(manifold, csr, xt, c_in, c_out=None, act_code=None):
     fuse = act_code is not None
     _lib.call(f"hd_{manifold}_agg" + _sfx(x2), _p(csr.rowptr), _p(csr.col), _p(csr.values(x2.dtype)), _p(x2),
               _p(out), csr.shape[0], x2.shape[1], curv(c_in), curv(c_out if fuse else c_in),
-              act_code if fuse else 0, 1 if fuse else 0, _stream())
+              act_code if fuse else 0, 1 if fuse else 0, _p(csr.long_rows) if csr.n_long else None, csr.n_long,
+              _stream())
     return out
 
 

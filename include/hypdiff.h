@@ -111,15 +111,19 @@ HD_DECL2(hd_rownorm, const void* x, void* out, int64_t rows, int64_t dim, void* 
  * out of range. */
 int hd_csr_from_coo(const int64_t* row, const int64_t* col_in, int64_t nnz, int64_t n_rows, int64_t n_cols,
                     int32_t* rowptr, int32_t* col, int32_t* flags, void* stream);
-/* plain torch.spmm(adj, x) :150 */
+/* plain torch.spmm(adj, x) :150.  long_rows (n_long entries, may be NULL/0): ids of the rows
+ * with more than 512 stored entries (power-law hubs); each of them is summed by a whole
+ * workgroup in 8 fixed slices instead of by one lane group. */
 HD_DECL2(hd_spmm_csr, const int32_t* rowptr, const int32_t* col, const void* val, const void* x, void* out,
-         int64_t rows, int64_t dim, void* stream)
+         int64_t rows, int64_t dim, const int32_t* long_rows, int64_t n_long, void* stream)
 /* proj(expmap0(spmm(adj, xt))) :150-151, xt = logmap0(x) already in the tangent space (:134);
  * fuse_act != 0 appends HypAct.forward (:170-173) with (c_in, c_out, act) in the same pass */
 HD_DECL2(hd_pb_agg, const int32_t* rowptr, const int32_t* col, const void* val, const void* xt, void* out,
-         int64_t rows, int64_t dim, hd_curv c_in, hd_curv c_out, int act, int fuse_act, void* stream)
+         int64_t rows, int64_t dim, hd_curv c_in, hd_curv c_out, int act, int fuse_act,
+         const int32_t* long_rows, int64_t n_long, void* stream)
 HD_DECL2(hd_hb_agg, const int32_t* rowptr, const int32_t* col, const void* val, const void* xt, void* out,
-         int64_t rows, int64_t dim, hd_curv c_in, hd_curv c_out, int act, int fuse_act, void* stream)
+         int64_t rows, int64_t dim, hd_curv c_in, hd_curv c_out, int act, int fuse_act,
+         const int32_t* long_rows, int64_t n_long, void* stream)
 
 /* ---- dense contractions ---------------------------------------------------------- */
 /* C[M,N] = epi(A[M,K] @ W[N,K]^T + bias[N]) on the exact-f32 matrix cores.
