@@ -153,6 +153,58 @@ __global__ __launch_bounds__(256) void standardize_k(const TX* __restrict__ x, T
     }
 }
 
+// ---- graph-level latent DDPM (ddpm.py / ddpm_utils.py), fp32 throughout -----------------
+// Model.forward noising, ddpm.py:95-104: idx per row, tables fp32.
+//   restrict == 0: sqrt(ab) * x + sqrt(1 - ab) * eps
+//   restrict != 0: pri * x + sqrt(ab) * x + sign(x) * sqrt(1 - ab) * eps,  pri = deta*tanh(sqrt(c)*t/2000)
+__global__ __launch_bounds__(256) void ddpm_noise_k(const float* __restrict__ x, const float* __restrict__ eps,
+                                                    const int64_t* __restrict__ idx,
+                                                    const float* __restrict__ alpha_bars, int64_t T,
+                                                    float* __restrict__ out, int64_t rows, int64_t dim,
+                                                    int restrict_, float deta, float sqrt_c, float horizon) {
+    const int64_t total = rows * dim;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / dim;
+        int64_t t = idx[r];
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        const float ab = alpha_bars[t];
+        const float sa = sqrtf(ab), sb = sqrtf(1.f - ab);
+        const float xv = x[i], e = eps[i];
+        if (!restrict_) {
+            out[i] = sa * xv + sb * e;
+        } else {
+            const float pri = deta * tanhf(sqrt_c * (float)idx[r] / horizon);
+            const float sg = xv > 0.f ? 1.f : (xv < 0.f ? -1.f : xv);
+            out[i] = pri * xv + sa * xv + sg * sb * e;
+        }
+    }
+}
+
+// DDPMSampler._one_diffusion_step, ddpm_utils.py:36-45 (target pred_noise, restrict False):
+//   x <- c1 * (x - c2 * eps) + c3 * noise,  c1 = sqrt(1/alpha_t), c2 = beta_t / sqrt(1 - ab_t),
+//   c3 = sqrt((1 - ab_{t-1}) / (1 - ab_t) * beta_t); noise may be NULL (idx == 0: zeros)
+__global__ __launch_bounds__(256) void ddpm_step_k(const float* __restrict__ x, const float* __restrict__ eps,
+                                                   const float* __restrict__ noise, float c1, float c2, float c3,
+                                                   float* __restrict__ out, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const float mu = c1 * (x[i] - c2 * eps[i]);
+        out[i] = mu + c3 * (noise ? noise[i] : 0.f);
+    }
+}
+
+// Backbone.forward, ddpm.py:39-41: h += embedding_layer(idx) (rows gathered from the (T, dim) table)
+__global__ __launch_bounds__(256) void embedding_add_k(float* __restrict__ h, const float* __restrict__ table,
+                                                       const int64_t* __restrict__ idx, int64_t T, int64_t rows,
+                                                       int64_t dim) {
+    const int64_t total = rows * dim;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / dim, c = i - r * dim;
+        int64_t t = idx[r];
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        h[i] = h[i] + table[t * dim + c];
+    }
+}
+
 inline int ew_grid(int64_t total) {
     int64_t b = (total + 255) / 256;
     if (b < 1) b = 1;
@@ -228,6 +280,35 @@ extern "C" int hd_mlp_pack_input(const void* x, int x_dtype, const void* t, int 
     else
         pack_input_k<float><<<g, 256, 0, (hipStream_t)st>>>((const float*)x, t, t_kind, (float)t_scalar, out, rows, dim, ld_out);
     return check_launch("hd_mlp_pack_input");
+}
+
+extern "C" int hd_ddpm_noise(const float* x, const float* eps, const int64_t* idx, const float* alpha_bars, int64_t T,
+                             float* out, int64_t rows, int64_t dim, int restrict_, double deta, double sqrt_c,
+                             double horizon, void* st) {
+    HD_REQUIRE(rows >= 0 && dim >= 1 && T >= 1, "hd_ddpm_noise: bad shape");
+    if (rows == 0) return HD_OK;
+    HD_REQUIRE(x && eps && idx && alpha_bars && out, "hd_ddpm_noise: null pointer");
+    ddpm_noise_k<<<ew_grid(rows * dim), 256, 0, (hipStream_t)st>>>(x, eps, idx, alpha_bars, T, out, rows, dim, restrict_,
+                                                                  (float)deta, (float)sqrt_c, (float)horizon);
+    return check_launch("hd_ddpm_noise");
+}
+
+extern "C" int hd_ddpm_step(const float* x, const float* eps, const float* noise, double c1, double c2, double c3,
+                            float* out, int64_t count, void* st) {
+    HD_REQUIRE(count >= 0, "hd_ddpm_step: bad count");
+    if (count == 0) return HD_OK;
+    HD_REQUIRE(x && eps && out, "hd_ddpm_step: null pointer");
+    ddpm_step_k<<<ew_grid(count), 256, 0, (hipStream_t)st>>>(x, eps, noise, (float)c1, (float)c2, (float)c3, out, count);
+    return check_launch("hd_ddpm_step");
+}
+
+extern "C" int hd_embedding_add(float* h, const float* table, const int64_t* idx, int64_t T, int64_t rows, int64_t dim,
+                                void* st) {
+    HD_REQUIRE(rows >= 0 && dim >= 1 && T >= 1, "hd_embedding_add: bad shape");
+    if (rows == 0) return HD_OK;
+    HD_REQUIRE(h && table && idx, "hd_embedding_add: null pointer");
+    embedding_add_k<<<ew_grid(rows * dim), 256, 0, (hipStream_t)st>>>(h, table, idx, T, rows, dim);
+    return check_launch("hd_embedding_add");
 }
 
 extern "C" int64_t hd_moments_workspace_doubles(void) { return 2 * kMomentBlocks; }

@@ -1,0 +1,110 @@
+"""Graph-level latent DDPM on HIP kernels -- drop-in for the reference's ddpm.py
+(`MLP`, `Backbone`, `Model`), the denoiser of diff_graphset.py (config 3).
+
+Same constructors and state_dict keys (`backbone.linear_model1.layers.N.*`,
+`backbone.embedding_layer.weight`, `backbone.linear_model2.layers.N.*`).  Every Linear
+is one MFMA GEMM launch with its bias, exact-erf GELU and residual add fused into the
+accumulator write-out (ddpm.py:17-27); the time embedding is added in place.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class MLP(nn.Module):
+    """ddpm.py:9-27"""
+
+    def __init__(self, dim_in, dim_hidden, dim_out, num_layer):
+        super().__init__()
+        self.layers = nn.ModuleList(
+            [nn.Linear(dim_in, dim_hidden)] + [nn.Linear(dim_hidden, dim_hidden) for _ in range(num_layer)] + [
+                nn.Linear(dim_hidden, dim_out)])
+        self.gelu = nn.GELU()
+
+    def forward(self, x):
+        ops._dev(x); ops._no_grad(x, self.layers[0].weight)
+        x = x.to(torch.float32).contiguous()
+        last = len(self.layers) - 1
+        for idx, layer in enumerate(self.layers):
+            w, b = layer.weight.detach(), layer.bias.detach()
+            if idx == 0:
+                x = ops.gemm(x, w, b, epi=1)                       # gelu(layer(x))
+            elif idx == last:
+                x = ops.gemm(x, w, b, epi=0)
+            else:
+                x = ops.gemm(x, w, b, epi=2, resid=x)              # x0 + gelu(layer(x0))
+        return x
+
+
+class Backbone(nn.Module):
+    """ddpm.py:30-41"""
+
+    def __init__(self, dim_in, dim_hidden, num_layer, n_steps):
+        super().__init__()
+        self.linear_model1 = MLP(dim_in, dim_hidden, dim_hidden, num_layer)
+        self.embedding_layer = nn.Embedding(n_steps, dim_hidden)
+        self.linear_model2 = MLP(dim_hidden, dim_hidden, dim_in, num_layer)
+
+    def forward(self, x, idx):
+        h = self.linear_model1(x)
+        tab = self.embedding_layer.weight.detach()
+        idx = idx.to(device=h.device, dtype=torch.int64).contiguous()
+        ops._lib.call("hd_embedding_add", ops._p(h), ops._p(tab), ops._p(idx), tab.shape[0], h.shape[0], h.shape[1],
+                      ops._stream())
+        return self.linear_model2(h)
+
+
+class Model(nn.Module):
+    """ddpm.py:44-111"""
+
+    def __init__(self, dim_in, dim_hidden, num_layer, T, beta_1, beta_T):
+        super().__init__()
+        self.beta = torch.linspace(start=beta_1, end=beta_T, steps=T)
+        self.alpha_bars = torch.cumprod(1 - self.beta, dim=0)
+        self.snr = (1 - self.alpha_bars) / self.alpha_bars
+        self.deta = 0.01
+        self.c = 1.0
+        self.backbone = Backbone(dim_in, dim_hidden, num_layer, T)
+        self._ab_dev = None
+
+    def getpri(self, t):
+        """ddpm.py:63-69"""
+        out = self.deta * torch.tanh(np.sqrt(self.c) * t / 2000)
+        return out.reshape(t.shape[0], 1)
+
+    def _alpha_bars_dev(self, device):
+        if self._ab_dev is None or self._ab_dev.device != torch.device(device):
+            self._ab_dev = self.alpha_bars.to(device).contiguous()
+        return self._ab_dev
+
+    def loss_fn(self, x, idx=None, target='pred_noise', epsilon=None):
+        """ddpm.py:71-85 (forward value; `idx` / `epsilon` optionally inject the draws)"""
+        output, epsilon, alpha_bar = self.forward(x, idx=idx, get_target=True, epsilon=epsilon, _train=True)
+        if target == 'pred_noise':
+            return (output - epsilon).square().mean()
+        return (output - x).square().mean()
+
+    def forward(self, x, idx=None, get_target=False, restrict=False, epsilon=None, _train=False):
+        """ddpm.py:87-111.  idx None (or `_train`): training-time noising at random / given
+        per-row steps; idx int: inference at that step on the already perturbed x."""
+        ops._dev(x)
+        if idx is None or _train:
+            if idx is None:
+                idx = torch.randint(0, len(self.alpha_bars), (x.size(0),)).to(x.device)
+            idx = idx.to(device=x.device, dtype=torch.int64).contiguous()
+            ab = self._alpha_bars_dev(x.device)
+            used_alpha_bars = ab[idx][:, None]
+            epsilon = torch.randn_like(x) if epsilon is None else epsilon
+            x = x.to(torch.float32).contiguous()
+            x_tilde = torch.empty_like(x)
+            ops._lib.call("hd_ddpm_noise", ops._p(x), ops._p(epsilon.contiguous()), ops._p(idx), ops._p(ab), ab.shape[0],
+                          ops._p(x_tilde), x.shape[0], x.shape[1], 1 if restrict else 0, self.deta,
+                          float(np.sqrt(self.c)), 2000.0, ops._stream())
+        else:
+            idx = torch.full((x.size(0),), int(idx), dtype=torch.int64, device=x.device)
+            x_tilde = x
+            used_alpha_bars = None
+        output = self.backbone(x_tilde, idx)
+        return (output, epsilon, used_alpha_bars) if get_target else output

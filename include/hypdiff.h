@@ -168,6 +168,20 @@ int hd_moments(const void* x, int dtype, int64_t count, double* workspace, doubl
 int hd_standardize(const void* x, void* out, int dtype, int64_t count, const double* moments3, int inverse,
                    void* stream);
 
+/* ---- graph-level latent DDPM, ddpm.py / ddpm_utils.py (config 3), fp32 ---------------- */
+/* Model.forward noising ddpm.py:95-104 (idx int64 per row, alpha_bars fp32 (T,)); restrict != 0
+ * selects the geometric-constraint form :103-104 with getpri :63-69 (deta, horizon 2000). */
+int hd_ddpm_noise(const float* x, const float* eps, const int64_t* idx, const float* alpha_bars, int64_t T,
+                  float* out, int64_t rows, int64_t dim, int restrict_, double deta, double sqrt_c,
+                  double horizon, void* stream);
+/* DDPMSampler._one_diffusion_step ddpm_utils.py:36-45 (pred_noise, restrict False):
+ * out = c1*(x - c2*eps) + c3*noise; noise NULL = zeros (idx 0) */
+int hd_ddpm_step(const float* x, const float* eps, const float* noise, double c1, double c2, double c3, float* out,
+                 int64_t count, void* stream);
+/* Backbone.forward ddpm.py:39-41: h[r] += table[idx[r]] in place */
+int hd_embedding_add(float* h, const float* table, const int64_t* idx, int64_t T, int64_t rows, int64_t dim,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -305,6 +305,91 @@ def capture_diffusion(out_dir):
     print("diffusion", len(store), "arrays")
 
 
+def capture_diffusionset(out_dir):
+    """models/direction_diffusionset.py at (G, N, D) = (4, 14, 14), K = 3 centres per graph."""
+    import models.direction_diffusionset as ds
+    store = {}
+    G_, Nn, D, K = 4, 14, 14, 3
+    rs = np.random.RandomState(77)
+    torch.manual_seed(1432)
+    diff = ds.diffusionset(types.SimpleNamespace(r=2.0, t=1.0), D, D).eval()
+    load_mlp(diff, D)
+    x = rs.standard_normal((G_, Nn, D)) * 0.2
+    x = (x / np.maximum(1.0, np.linalg.norm(x, axis=-1, keepdims=True) / 0.9)).astype(np.float32)
+    u0 = (rs.standard_normal((G_, K, D)) * 0.1).astype(np.float32)
+    labels = rs.randint(0, K, size=(G_, Nn)).astype(np.int64)
+    noise = rs.standard_normal((G_, Nn, D))
+    img = rs.standard_normal((G_, Nn, D)).astype(np.float32)
+    t = rs.randint(0, 200, size=G_).astype(np.int64)
+    for k, v in dict(x=x, u0=u0, labels=labels, noise=noise, img=img, t=t).items():
+        store["c/" + k] = v
+    u0t, tt = T(u0), T(t)
+    direction = [diff.manifold.logmap0(u, c=1.0) for u in u0t]
+    with torch.no_grad():
+        for r in (0, 1):
+            nz = T(noise)
+            store[f"q_sample/restrict{r}/out"] = N(diff.q_sample(T(x, torch.float64), tt, direction, nz, labels, u0t,
+                                                                 restrict=bool(r)))
+            store[f"q_sample/restrict{r}/noise_after"] = N(nz)
+        store["mlp/int_t"] = N(diff.mlp(T(x), tt))
+        for step in (150, 0):
+            pred, x0 = diff.p_sample(T(img), None, 1, direction, labels, u0t, step, None, True)
+            store[f"p_sample/t{step}/pred"], store[f"p_sample/t{step}/x_start"] = N(pred), N(x0)
+        for restrict in (False, True):
+            xin = T(x).clone()
+            nz = T(noise)
+            with injected(randint=lambda *a, **k: tt.clone(), randn_like=lambda *a, **k: nz.clone()):
+                loss = diff(xin, 1, labels, u0t, restrict=restrict, graphset=True)
+            store[f"forward/restrict{int(restrict)}/loss"] = N(loss)
+        xin = T(x).clone()
+        img0 = T(img)
+        with injected(randn=lambda *a, **k: img0.clone()):
+            ret = diff.p_sample_loop(xin, 1, labels, u0t, graphset=True)
+        store["p_sample_loop/ret"], store["p_sample_loop/x_after"] = N(ret), N(xin)
+    np.savez_compressed(os.path.join(out_dir, "diffusionset.npz"), **store)
+    print("diffusionset", len(store), "arrays")
+
+
+def capture_ddpm(out_dir):
+    """ddpm.Model / DDPMSampler (config 3): B latents of width 64, hidden 64, 3 layers, T=1000
+    (diff_graphset.py:191 uses hidden 512 x 10 layers; the small net keeps the fixture small)."""
+    import ddpm as rddpm
+    import ddpm_utils as rutils
+    store = {}
+    rs = np.random.RandomState(1432)
+    B, D, Hd, L, Tn = 10, 64, 64, 3, 1000
+    torch.manual_seed(1432)
+    model = rddpm.Model(D, Hd, L, Tn, 1e-4, 0.02).eval()
+    for k, v in model.state_dict().items():
+        store["sd/" + k] = N(v)
+    store["alpha_bars"] = N(model.alpha_bars)
+    x = T(rs.standard_normal((B, D)).astype(np.float32))
+    eps = T(rs.standard_normal((B, D)).astype(np.float32))
+    idx = T(rs.randint(0, Tn, size=B).astype(np.int64))
+    store["x"], store["eps"], store["idx"] = N(x), N(eps), N(idx)
+    with torch.no_grad():
+        store["backbone"] = N(model.backbone(x, idx))
+        store["infer_t500"] = N(model(x, 500))
+        for restrict in (False, True):
+            with injected(randint=lambda *a, **k: idx.clone(), randn_like=lambda *a, **k: eps.clone()):
+                out, e, ab = model(x, None, get_target=True, restrict=restrict)
+            store[f"train/restrict{int(restrict)}/out"] = N(out)
+            store[f"train/restrict{int(restrict)}/alpha_bar"] = N(ab)
+        with injected(randint=lambda *a, **k: idx.clone(), randn_like=lambda *a, **k: eps.clone()):
+            store["loss"] = N(model.loss_fn(x))
+        sampler = rutils.DDPMSampler(1e-4, 0.02, Tn, model, "cpu", (D,))
+        noises = [T(rs.standard_normal((B, D)).astype(np.float32)) for _ in range(3)]
+        it = iter(noises)
+        with injected(randn_like=lambda *a, **k: next(it).clone()):
+            gen = sampler._one_diffusion_step(x.clone(), torch.sign(x), False, 'pred_noise')
+            for i in range(3):
+                store[f"sampler/step{i}"] = N(next(gen))
+        for i, nz in enumerate(noises):
+            store[f"sampler/noise{i}"] = N(nz)
+    np.savez_compressed(os.path.join(out_dir, "ddpm.npz"), **store)
+    print("ddpm", len(store), "arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
@@ -320,6 +405,10 @@ def main():
         capture_layers(out)
     if a.only in ("", "diffusion"):
         capture_diffusion(out)
+    if a.only in ("", "diffusionset"):
+        capture_diffusionset(out)
+    if a.only in ("", "ddpm"):
+        capture_ddpm(out)
 
 
 if __name__ == "__main__":

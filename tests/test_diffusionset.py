@@ -1,0 +1,87 @@
+"""Graph-set direction diffusion (models/direction_diffusionset.py): oracle (row-folded
+restatement) vs reference-captured vectors on CPU; HIP path vs the same vectors on GPU."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close
+from oracle import diffusion as odiff, golden_inputs as gi
+from oracle.manifolds import pb_expmap, pb_logmap, pb_logmap0
+
+G_, Nn, D, K = 4, 14, 14, 3
+
+
+def _fold(g):
+    x = torch.from_numpy(g["c/x"])
+    u0 = torch.from_numpy(g["c/u0"]).reshape(G_ * K, D)
+    labels = (g["c/labels"] + np.arange(G_)[:, None] * K).reshape(-1)
+    t = torch.from_numpy(g["c/t"])
+    params = [(torch.from_numpy(w), torch.from_numpy(b)) for w, b in gi.mlp_params(D)]
+    return x, u0, labels, t, params
+
+
+def test_oracle_diffusionset_golden(golden):
+    g = golden("diffusionset")
+    x, u0, labels, t, params = _fold(g)
+    tb = odiff.schedule(200)
+    signs = odiff.sign_table(u0)
+    trow = t.repeat_interleave(Nn)
+    for r in (0, 1):
+        nz = torch.from_numpy(g["c/noise"]).reshape(-1, D).clone()
+        out = odiff.q_sample(x.double().reshape(-1, D), trow, nz, signs, labels, tb, restrict=bool(r))
+        assert_close(out.view(G_, Nn, D), g[f"q_sample/restrict{r}/out"], rtol=1e-7, what=f"q_sample {r}")
+        assert np.array_equal(nz.view(G_, Nn, D).numpy(), g[f"q_sample/restrict{r}/noise_after"])
+    assert_close(odiff.mlp_denoiser(x.reshape(-1, D), trow, params).view(G_, Nn, D), g["mlp/int_t"], what="mlp")
+    img = torch.from_numpy(g["c/img"]).reshape(-1, D)
+    for step in (150, 0):
+        raw = float(odiff.mlp_denoiser(img, torch.full((G_ * Nn,), step), params).abs().max())
+        pred, x0 = odiff.p_sample(img, step, signs, labels, tb, params)
+        assert_close(x0.view(G_, Nn, D), g[f"p_sample/t{step}/x_start"], what="x0", scale=raw)
+        assert_close(pred.view(G_, Nn, D), g[f"p_sample/t{step}/pred"], what="pred",
+                     scale=max(raw, float(np.abs(g[f"p_sample/t{step}/pred"]).max())))
+    # training loss, restrict False: x_start = logmap0(x) (:364-365); True: logmap at the centre
+    nz = torch.from_numpy(g["c/noise"]).reshape(-1, D)
+    for r in (0, 1):
+        xd = x.double().reshape(-1, D)
+        xs = pb_logmap(u0.double()[labels], xd, 1.0) if r else pb_logmap0(xd, 1.0)
+        xs = odiff.normalization(xs)
+        xt = odiff.q_sample(xs, trow, nz.clone(), signs, labels, tb, restrict=True)
+        out = odiff.mlp_denoiser(xt, trow / 200, params)
+        assert_close(torch.nn.functional.mse_loss(out, xs.float()), g[f"forward/restrict{r}/loss"], what=f"loss {r}")
+
+
+@pytest.mark.gpu
+def test_hip_diffusionset_golden(golden):
+    import types
+    from hypdiff_amd.models.direction_diffusionset import diffusionset
+    g = golden("diffusionset")
+    d = diffusionset(types.SimpleNamespace(r=2.0, t=1.0), D, D).eval()
+    sd = {}
+    for i, (w, b) in enumerate(gi.mlp_params(D), 1):
+        sd[f"fc{i}.weight"], sd[f"fc{i}.bias"] = torch.from_numpy(w), torch.from_numpy(b)
+    d.mlp.load_state_dict(sd)
+    C = lambda k, dt=None: (torch.from_numpy(np.array(g[k])).cuda() if dt is None else torch.from_numpy(np.array(g[k])).cuda().to(dt))
+    u0, labels, t = C("c/u0"), g["c/labels"], C("c/t")
+    params = [(torch.from_numpy(w), torch.from_numpy(b)) for w, b in gi.mlp_params(D)]
+    with torch.no_grad():
+        direction = d.directions(u0)
+        for r in (0, 1):
+            nz = C("c/noise")
+            out = d.q_sample(C("c/x", torch.float64), t, direction, nz, labels, u0, restrict=bool(r))
+            assert_close(out.cpu(), g[f"q_sample/restrict{r}/out"], rtol=1e-6, what=f"q_sample {r}")
+            assert np.array_equal(nz.cpu().numpy(), g[f"q_sample/restrict{r}/noise_after"])
+        assert_close(d.mlp(C("c/x"), t).cpu(), g["mlp/int_t"], what="mlp")
+        for step in (150, 0):
+            raw = float(odiff.mlp_denoiser(torch.from_numpy(g["c/img"]).reshape(-1, D), torch.full((G_ * Nn,), step),
+                                           params).abs().max())
+            pred, x0 = d.p_sample(C("c/img"), None, 1, direction, labels, u0, step, None, True)
+            assert_close(x0.cpu(), g[f"p_sample/t{step}/x_start"], what="x0", scale=raw, atol_scale=3e-6)
+            assert_close(pred.cpu(), g[f"p_sample/t{step}/pred"], what="pred", atol_scale=3e-6,
+                         scale=max(raw, float(np.abs(g[f"p_sample/t{step}/pred"]).max())))
+        for r in (0, 1):
+            loss = d(C("c/x"), 1, labels, u0, restrict=bool(r), graphset=True, t=t, noise=C("c/noise"))
+            assert_close(loss.cpu(), g[f"forward/restrict{r}/loss"], what=f"loss {r}")
+        x = C("c/x")
+        ret = d.p_sample_loop(x, 1, labels, u0, graphset=True, img=C("c/img"))
+        assert_close(x.cpu(), g["p_sample_loop/x_after"], what="x mutated")
+        assert_close(ret.cpu(), g["p_sample_loop/ret"], rtol=1e-3, atol_scale=1e-4, what="loop")
