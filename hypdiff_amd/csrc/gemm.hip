@@ -15,6 +15,7 @@
 // of slab t+1 are issued before the MFMAs of slab t (register staging).
 #include "hd_common.cuh"
 #include "../../include/hypdiff.h"
+#include <stdlib.h>
 
 using namespace hd;
 
@@ -24,7 +25,31 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 128, BK = 32, PITCH = BK + 4;
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf to < 1 ulp (max relative error 8e-8 against fp64 erf over [-6, 6]) in ~20 VALU ops:
+// two minimax polynomials (|x| <= 0.9277: odd polynomial; beyond: 1 - exp(poly)), both
+// evaluated and selected, no branches.  The library erff costs ~5x more, and 64 of them per
+// lane made the write-out of a 128x128 tile ~15 % of a wavefront's lifetime.
+__device__ __forceinline__ float erf_fast(float a) {
+    const float t = fabsf(a), s = a * a;
+    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = fmaf(r, s, u);
+    r = fmaf(r, t, -1.06777877e-1f);
+    r = fmaf(r, t, -6.34846687e-1f);
+    r = fmaf(r, t, -1.28717512e-1f);
+    r = fmaf(r, t, -t);
+    r = 1.0f - __expf(r);
+    r = copysignf(r, a);
+    float q = -5.96761703e-4f;
+    q = fmaf(q, s, 4.99119423e-3f);
+    q = fmaf(q, s, -2.67681349e-2f);
+    q = fmaf(q, s, 1.12819925e-1f);
+    q = fmaf(q, s, -3.76125336e-1f);
+    q = fmaf(q, s, 1.28379166e-1f);
+    q = fmaf(q, a, a);
+    return t > 0.927734375f ? r : q;
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 
 // epi: 0 none, 1 gelu, 2 residual + gelu (ddpm.py:20-22: x0 + gelu(layer(x0)))
 template <int BNT>
@@ -55,29 +80,69 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A
     const int srow = tid >> 3, skq = (tid & 7) * 4;
     float4 ra[BM / 32], rw[BNT / 32];
 
-    auto gload = [&](int k0) {
-        const bool kin = (k0 + skq) < K;
+    // Register staging, written as straight-line macros (a lambda capturing the arrays makes
+    // them addressable and hipcc then parks them in scratch memory).  Loads are unconditional:
+    // row and k are clamped to valid addresses so that no branch and no early s_waitcnt sits
+    // between their issue and the MFMAs; a slab position beyond K is zeroed when the registers
+    // are written to LDS one iteration later.
+    bool kinA = true;
+    const float* pA[BM / 32];
+    const float* pW[BNT / 32];
 #pragma unroll
-        for (int p = 0; p < BM / 32; ++p) {
-            int r = m0 + srow + 32 * p;
-            r = r < M ? r : M - 1;
-            ra[p] = kin ? *reinterpret_cast<const float4*>(A + (size_t)r * lda + k0 + skq) : make_float4(0, 0, 0, 0);
-        }
+    for (int p = 0; p < BM / 32; ++p) {
+        int r = m0 + srow + 32 * p;
+        r = r < M ? r : M - 1;
+        pA[p] = A + (size_t)r * lda;
+    }
 #pragma unroll
-        for (int p = 0; p < BNT / 32; ++p) {
-            int r = n0 + srow + 32 * p;
-            r = r < N ? r : N - 1;
-            rw[p] = kin ? *reinterpret_cast<const float4*>(W + (size_t)r * ldw + k0 + skq) : make_float4(0, 0, 0, 0);
-        }
-    };
-    auto sstore = [&]() {
-#pragma unroll
-        for (int p = 0; p < BM / 32; ++p)
-            *reinterpret_cast<float4*>(&sA[(srow + 32 * p) * PITCH + skq]) = ra[p];
-#pragma unroll
-        for (int p = 0; p < BNT / 32; ++p)
-            *reinterpret_cast<float4*>(&sW[(srow + 32 * p) * PITCH + skq]) = rw[p];
-    };
+    for (int p = 0; p < BNT / 32; ++p) {
+        int r = n0 + srow + 32 * p;
+        r = r < N ? r : N - 1;
+        pW[p] = W + (size_t)r * ldw;
+    }
+#define HD_GLOAD(RA, RW, KIN, k0)                                                           \
+    {                                                                                       \
+        KIN = ((k0) + skq) < K;                                                             \
+        const int kk = KIN ? (k0) + skq : K - 4;                                            \
+        _Pragma("unroll") for (int p = 0; p < BM / 32; ++p)                                 \
+            RA[p] = *reinterpret_cast<const float4*>(pA[p] + kk);                           \
+        _Pragma("unroll") for (int p = 0; p < BNT / 32; ++p)                                \
+            RW[p] = *reinterpret_cast<const float4*>(pW[p] + kk);                           \
+    }
+#define HD_SSTORE(RA, RW, KIN)                                                              \
+    {                                                                                       \
+        _Pragma("unroll") for (int p = 0; p < BM / 32; ++p) {                               \
+            float4 v = RA[p];                                                               \
+            v.x = KIN ? v.x : 0.f; v.y = KIN ? v.y : 0.f; v.z = KIN ? v.z : 0.f; v.w = KIN ? v.w : 0.f; \
+            *reinterpret_cast<float4*>(&sA[(srow + 32 * p) * PITCH + skq]) = v;             \
+        }                                                                                   \
+        _Pragma("unroll") for (int p = 0; p < BNT / 32; ++p) {                              \
+            float4 v = RW[p];                                                               \
+            v.x = KIN ? v.x : 0.f; v.y = KIN ? v.y : 0.f; v.z = KIN ? v.z : 0.f; v.w = KIN ? v.w : 0.f; \
+            *reinterpret_cast<float4*>(&sW[(srow + 32 * p) * PITCH + skq]) = v;             \
+        }                                                                                   \
+    }
+// one K slab: fragments from LDS, 16 * 2 * NT MFMAs
+#define HD_COMPUTE()                                                                        \
+    {                                                                                       \
+        float4 fa[2][4], fw[NT][4];                                                         \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                     \
+            const float* pa = &sA[(wr * 64 + i * 32 + fi) * PITCH + fh * 16];               \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) fa[i][q] = *reinterpret_cast<const float4*>(pa + 4 * q); \
+        }                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                    \
+            const float* pw = &sW[(wc * (BNT / 2) + j * 32 + fi) * PITCH + fh * 16];        \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) fw[j][q] = *reinterpret_cast<const float4*>(pw + 4 * q); \
+        }                                                                                   \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                       \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                   \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i)                               \
+                    _Pragma("unroll") for (int j = 0; j < NT; ++j) {                        \
+                        const float a = reinterpret_cast<const float*>(&fa[i][q])[e];       \
+                        const float b = reinterpret_cast<const float*>(&fw[j][q])[e];       \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0); \
+                    }                                                                       \
+    }
 
     f32x16 acc[2][NT];
 #pragma unroll
@@ -89,40 +154,23 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A
 
     const int fi = lane & 31, fh = lane >> 5;
     const int nk = (K + BK - 1) / BK;
-    gload(0);
+    // Software pipeline: while slab t is multiplied out of LDS the loads of slab t+1 are in
+    // flight into registers.  The sched_barrier keeps the loads where they are written: hipcc
+    // otherwise sinks them below the MFMAs to reuse the fragment registers, and the next
+    // iteration then waits out the full memory latency.  (A second register set / prefetch
+    // distance 2 was measured: no gain, 32 more VGPRs.)
+    HD_GLOAD(ra, rw, kinA, 0)
     for (int kt = 0; kt < nk; ++kt) {
-        sstore();
+        HD_SSTORE(ra, rw, kinA)
         __syncthreads();
-        if (kt + 1 < nk) gload((kt + 1) * BK);
-        float4 fa[2][4], fw[NT][4];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float* pa = &sA[(wr * 64 + i * 32 + fi) * PITCH + fh * 16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) fa[i][q] = *reinterpret_cast<const float4*>(pa + 4 * q);
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const float* pw = &sW[(wc * (BNT / 2) + j * 32 + fi) * PITCH + fh * 16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) fw[j][q] = *reinterpret_cast<const float4*>(pw + 4 * q);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        const float a = reinterpret_cast<const float*>(&fa[i][q])[e];
-                        const float b = reinterpret_cast<const float*>(&fw[j][q])[e];
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
-                    }
-            }
-        }
+        HD_GLOAD(ra, rw, kinA, (kt + 1) * BK)      // past the end: clamped re-read, never stored
+        __builtin_amdgcn_sched_barrier(0);
+        HD_COMPUTE()
         __syncthreads();
     }
+#undef HD_GLOAD
+#undef HD_SSTORE
+#undef HD_COMPUTE
 
     // C/D map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
@@ -198,18 +246,30 @@ extern "C" int hd_gemm_f32(const void* A, const void* W, const void* bias, const
     HD_REQUIRE(lda >= K && ldw >= K && ldc >= N, "hd_gemm_f32: leading dimension too small");
     HD_REQUIRE(epi >= 0 && epi <= 2 && (epi != 2 || resid), "hd_gemm_f32: bad epilogue / missing residual");
     const dim3 blk(256);
-    // narrow block tile when it wastes fewer padded columns or is needed to fill 256 CUs
-    const int64_t t128 = ((N + 127) / 128) * ((M + 127) / 128);
-    const bool narrow = ((N + 63) / 64) * 64 < ((N + 127) / 128) * 128 || t128 < 256;
+    // Tile width and residency (workgroups per CU, capped by requesting unused dynamic LDS).
+    // Measured on MI355X over the denoiser / HypLinear shapes (M = 15 777, N,K in 512..900):
+    // the 128x64 tile at 4 workgroups per CU is best or within 1 % of best everywhere (less
+    // padding of N, more workgroups per CU to overlap the LDS hand-off and the write-out of
+    // one with the MFMAs of the others); large square problems prefer 128x128 at 2 per CU.
     const int tiles_m = (int)((M + BM - 1) / BM);
-    if (narrow) {
+    int best_w = 64, best_r = 4;
+    if (N >= 2048 && M >= 2048 && N % 128 == 0) { best_w = 128; best_r = 2; }
+    if (const char* e = getenv("HD_GEMM_TUNE")) {          // tuning hook: "<n|w><R>"
+        if (e[0] == 'n') best_w = 64; else if (e[0] == 'w') best_w = 128;
+        if (e[0] && e[1] >= '1' && e[1] <= '4') best_r = e[1] - '0';
+    }
+    // LDS per CU 160 KiB: R resident workgroups <=> each asks for more than 160/(R+1) KiB
+    const size_t static_lds = (size_t)(BM + best_w) * PITCH * sizeof(float);
+    size_t want = (size_t)(160 * 1024) / (best_r + 1) + 1024;
+    const size_t dyn = want > static_lds ? want - static_lds : 0;
+    if (best_w == 64) {
         const int tiles_n = (int)((N + 63) / 64);
-        gemm_f32_mfma<64><<<dim3((unsigned)(tiles_m * tiles_n)), blk, 0, (hipStream_t)st>>>(
+        gemm_f32_mfma<64><<<dim3((unsigned)(tiles_m * tiles_n)), blk, dyn, (hipStream_t)st>>>(
             (const float*)A, (const float*)W, (const float*)bias, (const float*)resid, (float*)C, (int)M, (int)N,
             (int)K, (int)lda, (int)ldw, (int)ldc, epi, tiles_m, tiles_n);
     } else {
         const int tiles_n = (int)((N + 127) / 128);
-        gemm_f32_mfma<128><<<dim3((unsigned)(tiles_m * tiles_n)), blk, 0, (hipStream_t)st>>>(
+        gemm_f32_mfma<128><<<dim3((unsigned)(tiles_m * tiles_n)), blk, dyn, (hipStream_t)st>>>(
             (const float*)A, (const float*)W, (const float*)bias, (const float*)resid, (float*)C, (int)M, (int)N,
             (int)K, (int)lda, (int)ldw, (int)ldc, epi, tiles_m, tiles_n);
     }

@@ -39,13 +39,14 @@ __global__ __launch_bounds__(kBlock) void row_map1(const T* __restrict__ in, T* 
 template <class Op, typename T, typename I, int G, int VEC>
 __global__ __launch_bounds__(kBlock) void row_map2(const T* __restrict__ a, const I* __restrict__ ia,
                                                    const T* __restrict__ b, T* __restrict__ out,
-                                                   int64_t n, int d, Op op) {
+                                                   int64_t n, int d, Op op, int64_t na) {
     constexpr int RPB = kBlock / G;
     Tile<T, G, VEC> x, y;
     x.init(d);
     y.init(d);
     for (int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / G; row < n; row += (int64_t)gridDim.x * RPB) {
-        const int64_t ra = ia ? (int64_t)ia[row] : row;
+        int64_t ra = ia ? (int64_t)ia[row] : row;
+        if (ia) ra = ra < 0 ? 0 : (ra >= na ? na - 1 : ra);      // a label outside the table must not fault
         x.load(a + ra * d);
         y.load(b + row * d);
         op(x, y, row);          // result left in y
@@ -69,6 +70,44 @@ __global__ __launch_bounds__(kBlock) void row_reduce2(const T* __restrict__ a, c
     }
 }
 
+// out[e] = post(op(h[ia[e]], h[ib[e]])): edge decoder, rows gathered by int64 index pairs
+// (models/base_models.py:152-159); fd != 0 applies the Fermi-Dirac map 1/(exp((s-r)/t)+1)
+template <class Op, typename T, int G, int VEC>
+__global__ __launch_bounds__(kBlock) void row_reduce2_gather(const T* __restrict__ h, const int64_t* __restrict__ pairs,
+                                                             int64_t pair_stride, int64_t n_rows, T* __restrict__ out,
+                                                             int64_t n, int d, Op op, int fd, T fr, T ft) {
+    constexpr int RPB = kBlock / G;
+    Tile<T, G, VEC> x, y;
+    x.init(d);
+    y.init(d);
+    for (int64_t e = (int64_t)blockIdx.x * RPB + threadIdx.x / G; e < n; e += (int64_t)gridDim.x * RPB) {
+        int64_t ia = pairs[e * pair_stride], ib = pairs[e * pair_stride + 1];
+        ia = ia < 0 ? 0 : (ia >= n_rows ? n_rows - 1 : ia);
+        ib = ib < 0 ? 0 : (ib >= n_rows ? n_rows - 1 : ib);
+        x.load(h + ia * d);
+        y.load(h + ib * d);
+        T s = op(x, y);
+        if (fd) s = T(1) / ((T)exp((double)((s - fr) / ft)) + T(1));
+        if (x.j == 0) out[e] = s;
+    }
+}
+
+template <typename T, class Op>
+inline int launch_reduce2_gather(const char* name, const T* h, const int64_t* pairs, int64_t n_rows, T* out, int64_t n,
+                                 int64_t d, Op op, int fd, double fr, double ft, hipStream_t st) {
+    HD_REQUIRE(n >= 0 && d >= 1 && n_rows >= 1, "%s: bad shape", name);
+    if (n == 0) return HD_OK;
+    HD_REQUIRE(h && pairs && out, "%s: null pointer", name);
+    const RowCfg c = pick_cfg<T>(d, is_aligned16(h));
+    HD_REQUIRE(c.ok, "%s: dim=%lld exceeds the register-tile limit", name, (long long)d);
+    return dispatch_cfg<T>(c, [&](auto g, auto v) {
+        constexpr int G = decltype(g)::value, V = decltype(v)::value;
+        row_reduce2_gather<Op, T, G, V><<<grid_for_rows(n, G), kBlock, 0, st>>>(h, pairs, 2, n_rows, out, n, (int)d, op,
+                                                                               fd, (T)fr, (T)ft);
+        return check_launch(name);
+    });
+}
+
 template <typename T, class Op>
 inline int launch_map1(const char* name, const T* in, T* out, int64_t n, int64_t d, Op op, hipStream_t st) {
     HD_REQUIRE(n >= 0 && d >= 1, "%s: bad shape rows=%lld dim=%lld", name, (long long)n, (long long)d);
@@ -85,7 +124,7 @@ inline int launch_map1(const char* name, const T* in, T* out, int64_t n, int64_t
 
 template <typename T, typename I, class Op>
 inline int launch_map2(const char* name, const T* a, const I* ia, const T* b, T* out, int64_t n, int64_t d,
-                       Op op, hipStream_t st) {
+                       Op op, hipStream_t st, int64_t na = 0) {
     HD_REQUIRE(n >= 0 && d >= 1, "%s: bad shape rows=%lld dim=%lld", name, (long long)n, (long long)d);
     if (n == 0) return HD_OK;
     HD_REQUIRE(a && b && out, "%s: null pointer", name);
@@ -93,7 +132,7 @@ inline int launch_map2(const char* name, const T* a, const I* ia, const T* b, T*
     HD_REQUIRE(c.ok, "%s: dim=%lld exceeds the register-tile limit", name, (long long)d);
     return dispatch_cfg<T>(c, [&](auto g, auto v) {
         constexpr int G = decltype(g)::value, V = decltype(v)::value;
-        row_map2<Op, T, I, G, V><<<grid_for_rows(n, G), kBlock, 0, st>>>(a, ia, b, out, n, (int)d, op);
+        row_map2<Op, T, I, G, V><<<grid_for_rows(n, G), kBlock, 0, st>>>(a, ia, b, out, n, (int)d, op, na);
         return check_launch(name);
     });
 }

@@ -137,13 +137,13 @@ HD_MAP2(hd_pb_logmap, B_LOGMAP)      // a = p1 (base point), b = p2
                             void* out, int64_t n, int64_t d, hd_curv c, void* st) {                    \
         HD_REQUIRE(labels && k >= 1, #fn ": labels/centres missing");                                  \
         return launch_map2<float, int32_t>(#fn "_f32", (const float*)centres, labels, (const float*)b, \
-                                           (float*)out, n, d, Op2<float, WHICH>{mk(c)}, (hipStream_t)st); \
+                                           (float*)out, n, d, Op2<float, WHICH>{mk(c)}, (hipStream_t)st, k); \
     }                                                                                                  \
     extern "C" int fn##_f64(const void* centres, const int32_t* labels, int64_t k, const void* b,     \
                             void* out, int64_t n, int64_t d, hd_curv c, void* st) {                    \
         HD_REQUIRE(labels && k >= 1, #fn ": labels/centres missing");                                  \
         return launch_map2<double, int32_t>(#fn "_f64", (const double*)centres, labels, (const double*)b, \
-                                            (double*)out, n, d, Op2<double, WHICH>{mk(c)}, (hipStream_t)st); \
+                                            (double*)out, n, d, Op2<double, WHICH>{mk(c)}, (hipStream_t)st, k); \
     }
 HD_MAP2_AT(hd_pb_expmap_at, B_EXPMAP)
 HD_MAP2_AT(hd_pb_logmap_at, B_LOGMAP)
@@ -161,6 +161,20 @@ HD_MAP2_AT(hd_pb_logmap_at, B_LOGMAP)
     }
 HD_SQDIST(hd_pb_sqdist, PB)
 HD_SQDIST(hd_hb_sqdist, HB)
+
+#define HD_DECODE(fn, M)                                                                                \
+    extern "C" int fn##_f32(const void* h, const int64_t* pairs, int64_t n_rows, void* out, int64_t n, \
+                            int64_t d, hd_curv c, int fermi_dirac, double r, double t, void* st) {      \
+        return launch_reduce2_gather<float>(#fn "_f32", (const float*)h, pairs, n_rows, (float*)out, n, d, \
+                                            OpSqdist<M<float>, float>{mk(c)}, fermi_dirac, r, t, (hipStream_t)st); \
+    }                                                                                                   \
+    extern "C" int fn##_f64(const void* h, const int64_t* pairs, int64_t n_rows, void* out, int64_t n, \
+                            int64_t d, hd_curv c, int fermi_dirac, double r, double t, void* st) {      \
+        return launch_reduce2_gather<double>(#fn "_f64", (const double*)h, pairs, n_rows, (double*)out, n, d, \
+                                             OpSqdist<M<double>, double>{mk(c)}, fermi_dirac, r, t, (hipStream_t)st); \
+    }
+HD_DECODE(hd_pb_edge_decode, PB)
+HD_DECODE(hd_hb_edge_decode, HB)
 
 #define HD_EPI(T, sfx)                                                                                   \
     extern "C" int hd_pb_matvec_epilogue_##sfx(const void* mx, const void* xnorm, void* out, int64_t n, \

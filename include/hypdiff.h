@@ -101,6 +101,14 @@ HD_DECL2(hd_hb_linear_epilogue, const void* mu, void* out, int64_t rows, int64_t
 HD_DECL2(hd_hb_hyp_act, const void* x, void* out, int64_t rows, int64_t dim, hd_curv c_in, hd_curv c_out,
          int act, void* stream)
 
+/* LPModel.decode, models/base_models.py:152-159: sqdist(h[idx[:,0]], h[idx[:,1]]) for int64 index
+ * pairs (n_pairs, 2) gathered in the kernel; fermi_dirac != 0 appends FermiDiracDecoder
+ * (layers/layers.py:85-87) probs = 1/(exp((sqdist - r)/t) + 1).  out (n_pairs,) */
+HD_DECL2(hd_pb_edge_decode, const void* h, const int64_t* pairs, int64_t n_rows, void* out, int64_t n_pairs,
+         int64_t dim, hd_curv c, int fermi_dirac, double r, double t, void* stream)
+HD_DECL2(hd_hb_edge_decode, const void* h, const int64_t* pairs, int64_t n_rows, void* out, int64_t n_pairs,
+         int64_t dim, hd_curv c, int fermi_dirac, double r, double t, void* stream)
+
 /* row L2 norms (unclamped), x.norm(dim=-1) of manifolds/poincare.py:95 -> out (rows,) */
 HD_DECL2(hd_rownorm, const void* x, void* out, int64_t rows, int64_t dim, void* stream)
 

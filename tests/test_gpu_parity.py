@@ -224,6 +224,20 @@ def test_hgcn_encode_golden(golden, kind, n, mname, c):
     with torch.no_grad():
         out = enc.encode(x, _adj(g, k0, n))
     assert_close(H(out), g[k + "encode"], rtol=3e-5, atol_scale=3e-6, what=k + "encode")
+    # LPModel: encode through the wrapper (zero time column prepended for the hyperboloid) + edge decoder
+    from hypdiff_amd.models.base_models import LPModel
+    largs = types.SimpleNamespace(manifold=mname, c=c, cuda=0, device="cuda:0", feat_dim=n, n_nodes=n, model="HGCN",
+                                  r=2.0, t=1.0, nb_false_edges=1, nb_edges=1, dim=dim, num_layers=2, act="relu",
+                                  dropout=0.0, bias=0, use_att=0, local_agg=0)
+    lp = LPModel(largs).cuda().eval()
+    for i, lyr in enumerate(lp.encoder.layers):
+        lyr.linear.load_state_dict({"weight": torch.from_numpy(g[k + f"W{i}"]), "bias": torch.from_numpy(g[k + f"b{i}"])})
+    with torch.no_grad():
+        emb, _, _, _ = lp.encode(G(g[k0 + "features"]), _adj(g, k0, n))
+        assert_close(H(emb), g[k + "encode"], rtol=3e-5, atol_scale=3e-6, what=k + "lp encode")
+        probs = lp.decode(G(g[k + "encode"]), G(g[k0 + "train_edges"]))
+    ex = olayers.lp_decode(mname, torch.from_numpy(g[k + "encode"]).double(), torch.from_numpy(g[k0 + "train_edges"]), c, 2.0, 1.0)
+    assert_close(H(probs), g[k + "decode_train"], what=k + "decode", exact=ex.numpy())
 
 
 # ---------------------------------------------------------------------------------
