@@ -145,6 +145,17 @@ def main():
     flops = sum(e[2] for e in events)
     gemm_ms = sum(e[0].elapsed_time(e[1]) for e in events)
     achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    # HBM bytes per GEMM launch from the PMC passes of the same command (profiles/, collected
+    # with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE; cannot be sampled from inside the process)
+    traffic, traffic_src = None, None
+    tp = os.path.join(ROOT, "profiles", "r01_bench_hbm_traffic.json")
+    if os.path.exists(tp):
+        try:
+            traffic = json.load(open(tp))["kernels"]["gemm_f32_mfma<64>"]["hbm_bytes_corrected"]
+            traffic_src = "profiles/r01_bench_hbm_traffic.json (rocprofv3 PMC, per-launch mean)"
+        except Exception:
+            traffic = None
+    alg_bytes = sum(e[3] for e in events) / max(1, len(events))
     rows_total = w["n"] * a.steps * world
     out = {
         "metric": "latent node-steps/sec (HGCN encode + DDPM step)",
@@ -156,8 +167,11 @@ def main():
                                "(mlp denoiser, T=%d tables)" % (w["n"], w["nnz"], a.dim, a.dim, T),
                    "rows_per_gpu": w["n"], "dim": a.dim, "timesteps": T, "parallelism": "graph-set shards x%d" % world},
         "roofline": {"bound": "mfma", "kernel": "gemm_f32_mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                     "launches": len(events), "gemm_ms_per_step": gemm_ms / a.steps},
+                     "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+                     "traffic_unit": "HBM bytes per launch (mean)", "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": alg_bytes, "launches": len(events),
+                     "gemm_ms_per_step": gemm_ms / a.steps,
+                     "memory_bound_kernels": "profiles/r01_kernel_roofline.jsonl (tools/bench_kernels.py)"},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w, a.dim, T)

@@ -177,7 +177,7 @@ def gemm(a, w, bias=None, epi=0, resid=None, out=None):
               w.stride(0), out.stride(0), epi, _stream())
     if ev is not None:
         e1.record()
-        ev.append((e0, e1, 2.0 * M * N * K))
+        ev.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)))
     return out
 
 
