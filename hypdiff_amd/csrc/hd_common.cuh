@@ -54,6 +54,15 @@ __device__ __forceinline__ double dpp_get(double v) {
     const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, false);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
+__device__ __forceinline__ float lane_bcast0(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+}
+__device__ __forceinline__ double lane_bcast0(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), 0);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 0);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ float lane_bcast63(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
@@ -184,8 +193,32 @@ struct Tile {
             }
         }
     }
-    // column 0 of the row, broadcast to the group
-    __device__ __forceinline__ T first() const { return group_sum<G>(j == 0 ? v[0] : T(0)); }
+    // column 0 of the row, broadcast to the group (lane 0 of the group holds it)
+    __device__ __forceinline__ T first() const {
+        if constexpr (G == 64) return lane_bcast0(v[0]);
+        else return __shfl(v[0], (int)(threadIdx.x & 63 & ~(G - 1)), 64);
+    }
+    // sum of squares of the row (s1) and of act(row) (s2) for a positively homogeneous
+    // activation (identity: slope 1, relu: 0, leaky_relu: 0.01 on the negative side), one
+    // sweep over the registers and two interleaved butterflies; `skip` drops column 0
+    __device__ __forceinline__ void sumsq_pair(int skip, T neg_slope, T& s1, T& s2) const {
+        T a = T(0), b = T(0);
+#pragma unroll
+        for (int k = 0; k < CHMAX; ++k) {
+            if (k < ch) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    T x = v[k * VEC + e];
+                    if (k == 0 && e == 0) x = (skip && j == 0) ? T(0) : x;
+                    const T y = x > T(0) ? x : (x != x ? x : neg_slope * x);
+                    a += x * x;
+                    b += y * y;
+                }
+            }
+        }
+        s1 = group_sum<G>(a);
+        s2 = group_sum<G>(b);
+    }
     __device__ __forceinline__ void set_first(T x) {
         if (j == 0) v[0] = x;
     }

@@ -35,6 +35,14 @@ __device__ __forceinline__ double hd_cosh(double x) { return cosh(x); }
 __device__ __forceinline__ float hd_sinh(float x) { return sinhf(x); }
 __device__ __forceinline__ double hd_sinh(double x) { return sinh(x); }
 
+// 1-ulp hardware reciprocal / square root for per-row factors that feed no cancellation
+// (a relative error of 1e-7 in a scale factor is 100x below the parity bar); everything that
+// enters artanh / arcosh keeps the correctly rounded forms.
+__device__ __forceinline__ float fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ double fast_div(double a, double b) { return a / b; }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }
+
 // utils/math_utils.py:14-15
 template <typename T> __device__ __forceinline__ T tanh15(T x) { return hd_tanh(clamp15(x)); }
 template <typename T> __device__ __forceinline__ T cosh15(T x) { return hd_cosh(clamp15(x)); }
@@ -231,9 +239,56 @@ template <typename T> __device__ __forceinline__ T apply_act(T x, int act) {
     }
 }
 
+// HypAct for a positively homogeneous activation (identity / relu / leaky_relu).
+// act(f*x) = f*act(x) for the positive per-row factor f of logmap0, so every norm of the
+// chain logmap0 -> act -> expmap0 -> proj follows from TWO sums over the input row,
+// s1 = |x|^2 and s2 = |act(x)|^2 (|f*u| = f*|u|: the literal recomputation differs by
+// rounding only), and the row is rescaled once: one sweep of reductions instead of four
+// dependent ones, which is what kept this map VALU-bound instead of HBM-bound.
+template <typename T, class TL>
+__device__ __forceinline__ void hyp_act_homog(PB<T>*, TL& r, const Curv& cin, const Curv& cout, T slope) {
+    T s1, s2;
+    r.sumsq_pair(0, slope, s1, s2);
+    const T sci = (T)cin.sc, sco = (T)cout.sc;
+    const T n1 = clamp_min(hd_sqrt(s1), (T)kMinNorm);
+    const T f1 = fast_div((T)(1.0 / cin.sc) * artanh_ref(sci * n1), n1);  // logmap0 (poincare.py:79-83)
+    const T m = f1 * fast_sqrt(s2);                                       // |act(logmap0(x))|
+    const T n2 = clamp_min(m, (T)kMinNorm);
+    const T f2 = fast_div(tanh15(sco * n2), sco * n2);                    // expmap0 (:73-77)
+    const T n3 = clamp_min(f2 * m, (T)kMinNorm);
+    const T maxnorm = (T)((1.0 - Lim<T>::pb_eps) / cout.sc);
+    const T f3 = n3 > maxnorm ? fast_div(maxnorm, n3) : T(1);             // proj (:42-47)
+    const T f = f1 * f2 * f3;
+    r.map([=](T x) { return f * (x > T(0) ? x : (x != x ? x : slope * x)); });
+}
+template <typename T, class TL>
+__device__ __forceinline__ void hyp_act_homog(HB<T>*, TL& r, const Curv& cin, const Curv& cout, T slope) {
+    T s1, s2;
+    const T x0 = r.first();
+    r.sumsq_pair(1, slope, s1, s2);
+    const T sKi = (T)cin.sK, sKo = (T)cout.sK;
+    const T n1 = clamp_min(hd_sqrt(s1), (T)kMinNorm);
+    const T theta = clamp_min(x0 / sKi, (T)(1.0 + Lim<T>::hb_eps));
+    const T f1 = fast_div(sKi * arcosh_ref(theta), n1);                   // logmap0 (hyperboloid.py:103-113)
+    const T m = f1 * fast_sqrt(s2);                                       // |act(logmap0(x))| (spatial)
+    const T n2 = clamp_min(m, (T)kMinNorm);
+    T shv, chv;
+    sinhcosh15(n2 * (T)(1.0 / cout.sK), shv, chv);                        // expmap0 (:90-101)
+    const T f2 = fast_div(sKo * shv, n2);
+    const T ns = f2 * m;                                                  // spatial norm after expmap0
+    const T t0 = hd_sqrt(clamp_min((T)cout.K + ns * ns, (T)Lim<T>::hb_eps));   // proj (:43-52), idempotent
+    const T f = f1 * f2;
+    r.map([=](T x) { return f * (x > T(0) ? x : (x != x ? x : slope * x)); });
+    r.set_first(t0);
+}
+
 // layers/hyp_layers.py:170-173: logmap0(c_in) -> act -> proj_tan0 -> expmap0(c_out) -> proj(c_out)
 template <class M, typename T, class TL>
 __device__ __forceinline__ void hyp_act(TL& r, const Curv& cin, const Curv& cout, int act) {
+    if (act == ACT_IDENTITY || act == ACT_RELU || act == ACT_LEAKY_RELU) {
+        hyp_act_homog<T>((M*)nullptr, r, cin, cout, act == ACT_IDENTITY ? T(1) : (act == ACT_RELU ? T(0) : T(0.01)));
+        return;
+    }
     M::logmap0(r, cin);
     r.map([=](T x) { return apply_act(x, act); });
     M::proj_tan0(r, cout);

@@ -21,52 +21,121 @@ inline int dispatch_cfg(const RowCfg& c, F&& f) {
     return f(IC<64>{}, IC<V>{});
 }
 
-// out[row] = op(in[row])
-template <class Op, typename T, int G, int VEC>
+// Rows per lane group and loop iteration.  A row that needs only 4 (8) of the 16 tile
+// registers leaves room for 4 (2) independent rows per group: their loads are issued back
+// to back and their norm -> transcendental -> rescale chains interleave, which is what a
+// latency-bound composite map (HypAct: three dependent reductions per row) needs to keep
+// HBM busy.  Batching is used when the launch still has >= 1024 workgroups; fp64 rows and
+// short launches run one row per group (REGS = 16).
+template <typename T>
+inline int pick_regs(const RowCfg& c, int64_t n, int64_t d) {
+    if (sizeof(T) != 4) return kRegs;
+    const int64_t span = (int64_t)c.g * c.vec;
+    const int need = (int)((d + span - 1) / span) * c.vec;
+    int regs = need <= 4 ? 4 : (need <= 8 ? 8 : kRegs);
+    const int64_t rpb = kBlock / c.g;
+    while (regs < kRegs && n / (rpb * (kRegs / regs)) < 1024) regs *= 2;
+    return regs;
+}
+
+// calls f(IC<G>, IC<VEC>, IC<REGS>)
+template <typename T, class F>
+inline int dispatch_cfg_regs(const RowCfg& c, int regs, F&& f) {
+    return dispatch_cfg<T>(c, [&](auto g, auto v) {
+        constexpr int V = decltype(v)::value;
+        if constexpr (sizeof(T) == 4) {
+            if (regs == 4 && V <= 4) return f(g, v, IC<4>{});
+            if (regs == 8) return f(g, v, IC<8>{});
+        }
+        return f(g, v, IC<kRegs>{});
+    });
+}
+
+inline int grid_for_rows_batched(int64_t rows, int g, int r) {
+    const int64_t rows_per_block = (int64_t)(kBlock / g) * r;
+    int64_t blocks = (rows + rows_per_block - 1) / rows_per_block;
+    if (blocks < 1) blocks = 1;
+    const int64_t cap = 256 * 16;
+    return (int)(blocks < cap ? blocks : cap);
+}
+
+// out[row] = op(in[row]).  R = kRegs / REGS rows per group and iteration; a slot past the end
+// recomputes the last row and skips the store, so loads and reductions stay unconditional.
+template <class Op, typename T, int G, int VEC, int REGS>
 __global__ __launch_bounds__(kBlock) void row_map1(const T* __restrict__ in, T* __restrict__ out,
                                                    int64_t n, int d, Op op) {
-    constexpr int RPB = kBlock / G;
-    Tile<T, G, VEC> r;
-    r.init(d);
-    for (int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / G; row < n; row += (int64_t)gridDim.x * RPB) {
-        r.load(in + row * d);
-        op(r, row);
-        r.store(out + row * d);
+    constexpr int RPB = kBlock / G, R = kRegs / REGS;
+    Tile<T, G, VEC, REGS> r[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) r[i].init(d);
+    const int g = threadIdx.x / G;
+    for (int64_t base = (int64_t)blockIdx.x * (RPB * R); base < n; base += (int64_t)gridDim.x * (RPB * R)) {
+        int64_t row[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            row[i] = base + i * RPB + g;
+            r[i].load(in + (row[i] < n ? row[i] : n - 1) * d);
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) op(r[i], row[i] < n ? row[i] : n - 1);
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+            if (row[i] < n) r[i].store(out + row[i] * d);
     }
 }
 
 // out[row] = op(a[row or gathered], b[row]); ia (optional) gathers rows of a
-template <class Op, typename T, typename I, int G, int VEC>
+template <class Op, typename T, typename I, int G, int VEC, int REGS>
 __global__ __launch_bounds__(kBlock) void row_map2(const T* __restrict__ a, const I* __restrict__ ia,
                                                    const T* __restrict__ b, T* __restrict__ out,
                                                    int64_t n, int d, Op op, int64_t na) {
-    constexpr int RPB = kBlock / G;
-    Tile<T, G, VEC> x, y;
-    x.init(d);
-    y.init(d);
-    for (int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / G; row < n; row += (int64_t)gridDim.x * RPB) {
-        int64_t ra = ia ? (int64_t)ia[row] : row;
-        if (ia) ra = ra < 0 ? 0 : (ra >= na ? na - 1 : ra);      // a label outside the table must not fault
-        x.load(a + ra * d);
-        y.load(b + row * d);
-        op(x, y, row);          // result left in y
-        y.store(out + row * d);
+    constexpr int RPB = kBlock / G, R = kRegs / REGS;
+    Tile<T, G, VEC, REGS> x[R], y[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) { x[i].init(d); y[i].init(d); }
+    const int g = threadIdx.x / G;
+    for (int64_t base = (int64_t)blockIdx.x * (RPB * R); base < n; base += (int64_t)gridDim.x * (RPB * R)) {
+        int64_t row[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            row[i] = base + i * RPB + g;
+            const int64_t rl = row[i] < n ? row[i] : n - 1;
+            int64_t ra = ia ? (int64_t)ia[rl] : rl;
+            if (ia) ra = ra < 0 ? 0 : (ra >= na ? na - 1 : ra);      // a label outside the table must not fault
+            x[i].load(a + ra * d);
+            y[i].load(b + rl * d);
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) op(x[i], y[i], row[i] < n ? row[i] : n - 1);      // result left in y
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+            if (row[i] < n) y[i].store(out + row[i] * d);
     }
 }
 
 // out[row] = scalar op(a[row], b[row])
-template <class Op, typename T, int G, int VEC>
+template <class Op, typename T, int G, int VEC, int REGS>
 __global__ __launch_bounds__(kBlock) void row_reduce2(const T* __restrict__ a, const T* __restrict__ b,
                                                       T* __restrict__ out, int64_t n, int d, Op op) {
-    constexpr int RPB = kBlock / G;
-    Tile<T, G, VEC> x, y;
-    x.init(d);
-    y.init(d);
-    for (int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / G; row < n; row += (int64_t)gridDim.x * RPB) {
-        x.load(a + row * d);
-        y.load(b + row * d);
-        const T s = op(x, y);
-        if (x.j == 0) out[row] = s;
+    constexpr int RPB = kBlock / G, R = kRegs / REGS;
+    Tile<T, G, VEC, REGS> x[R], y[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) { x[i].init(d); y[i].init(d); }
+    const int g = threadIdx.x / G;
+    for (int64_t base = (int64_t)blockIdx.x * (RPB * R); base < n; base += (int64_t)gridDim.x * (RPB * R)) {
+        int64_t row[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            row[i] = base + i * RPB + g;
+            const int64_t rl = row[i] < n ? row[i] : n - 1;
+            x[i].load(a + rl * d);
+            y[i].load(b + rl * d);
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const T s = op(x[i], y[i]);
+            if (x[i].j == 0 && row[i] < n) out[row[i]] = s;
+        }
     }
 }
 
@@ -115,9 +184,9 @@ inline int launch_map1(const char* name, const T* in, T* out, int64_t n, int64_t
     HD_REQUIRE(in && out, "%s: null pointer", name);
     const RowCfg c = pick_cfg<T>(d, is_aligned16(in) && is_aligned16(out));
     HD_REQUIRE(c.ok, "%s: dim=%lld exceeds the register-tile limit (use the streaming entry point)", name, (long long)d);
-    return dispatch_cfg<T>(c, [&](auto g, auto v) {
-        constexpr int G = decltype(g)::value, V = decltype(v)::value;
-        row_map1<Op, T, G, V><<<grid_for_rows(n, G), kBlock, 0, st>>>(in, out, n, (int)d, op);
+    return dispatch_cfg_regs<T>(c, pick_regs<T>(c, n, d), [&](auto g, auto v, auto rg) {
+        constexpr int G = decltype(g)::value, V = decltype(v)::value, RG = decltype(rg)::value;
+        row_map1<Op, T, G, V, RG><<<grid_for_rows_batched(n, G, kRegs / RG), kBlock, 0, st>>>(in, out, n, (int)d, op);
         return check_launch(name);
     });
 }
@@ -130,9 +199,10 @@ inline int launch_map2(const char* name, const T* a, const I* ia, const T* b, T*
     HD_REQUIRE(a && b && out, "%s: null pointer", name);
     const RowCfg c = pick_cfg<T>(d, is_aligned16(a) && is_aligned16(b) && is_aligned16(out));
     HD_REQUIRE(c.ok, "%s: dim=%lld exceeds the register-tile limit", name, (long long)d);
-    return dispatch_cfg<T>(c, [&](auto g, auto v) {
-        constexpr int G = decltype(g)::value, V = decltype(v)::value;
-        row_map2<Op, T, I, G, V><<<grid_for_rows(n, G), kBlock, 0, st>>>(a, ia, b, out, n, (int)d, op, na);
+    return dispatch_cfg_regs<T>(c, pick_regs<T>(c, n, d), [&](auto g, auto v, auto rg) {
+        constexpr int G = decltype(g)::value, V = decltype(v)::value, RG = decltype(rg)::value;
+        row_map2<Op, T, I, G, V, RG><<<grid_for_rows_batched(n, G, kRegs / RG), kBlock, 0, st>>>(a, ia, b, out, n,
+                                                                                               (int)d, op, na);
         return check_launch(name);
     });
 }
@@ -145,9 +215,10 @@ inline int launch_reduce2(const char* name, const T* a, const T* b, T* out, int6
     HD_REQUIRE(a && b && out, "%s: null pointer", name);
     const RowCfg c = pick_cfg<T>(d, is_aligned16(a) && is_aligned16(b));
     HD_REQUIRE(c.ok, "%s: dim=%lld exceeds the register-tile limit", name, (long long)d);
-    return dispatch_cfg<T>(c, [&](auto g, auto v) {
-        constexpr int G = decltype(g)::value, V = decltype(v)::value;
-        row_reduce2<Op, T, G, V><<<grid_for_rows(n, G), kBlock, 0, st>>>(a, b, out, n, (int)d, op);
+    return dispatch_cfg_regs<T>(c, pick_regs<T>(c, n, d), [&](auto g, auto v, auto rg) {
+        constexpr int G = decltype(g)::value, V = decltype(v)::value, RG = decltype(rg)::value;
+        row_reduce2<Op, T, G, V, RG><<<grid_for_rows_batched(n, G, kRegs / RG), kBlock, 0, st>>>(a, b, out, n, (int)d,
+                                                                                               op);
         return check_launch(name);
     });
 }
