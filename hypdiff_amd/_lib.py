@@ -24,6 +24,14 @@ _at = [P, P, I64, P, P, I64, I64, HdCurv, P]
 _act = [P, P, I64, I64, HdCurv, HdCurv, c_int, P]
 _agg = [P, P, P, P, P, I64, I64, HdCurv, HdCurv, c_int, c_int, P, I64, P]
 
+# entry points returning an int64 size instead of a status: name -> argtypes
+SIZE_QUERIES = {
+    "hd_moments_workspace_doubles": [],
+    "hd_gemm_tn_workspace_floats": [I64, I64, I64],
+    "hd_colsum_workspace_floats": [I64, I64],
+    "hd_mse_workspace_doubles": [],
+}
+
 # name -> argtypes; names ending in "*" exist as _f32 and _f64
 SIGNATURES = {
     "hd_pb_proj*": _map1, "hd_pb_expmap0*": _map1, "hd_pb_logmap0*": _map1, "hd_pb_expmap0_proj*": _map1,
@@ -43,6 +51,12 @@ SIGNATURES = {
     "hd_pb_agg*": _agg, "hd_hb_agg*": _agg,
     "hd_gemm_f32": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, c_int, P],
     "hd_gemm_f64": [P, P, P, P, I64, I64, I64, I64, I64, I64, P],
+    "hd_gemm_f32_ex": [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, c_int, P],
+    "hd_gemm_tn_f32": [P, P, P, I64, I64, I64, I64, I64, I64, P, P],
+    "hd_transpose_f32": [P, P, I64, I64, I64, I64, P],
+    "hd_colsum_f32": [P, P, I64, I64, I64, P, P],
+    "hd_mse_forward_f32": [P, P, P, I64, P, P, P],
+    "hd_mse_backward_f32": [P, P, P, I64, P],
     "hd_q_sample": [P, c_int, P, c_int, P, P, P, I64, P, P, I64, P, I64, I64, c_int, c_double, c_double,
                     c_double, P],
     "hd_p_sample_update": [P, c_int, P, P, P, I64, c_double, c_double, c_double, c_double, I64, I64, P, I64,
@@ -60,7 +74,7 @@ _lib = None
 
 
 def exported_names():
-    out = ["hd_version", "hd_last_error", "hd_moments_workspace_doubles"]
+    out = ["hd_version", "hd_last_error"] + list(SIZE_QUERIES)
     for k in SIGNATURES:
         out += [k[:-1] + "_f32", k[:-1] + "_f64"] if k.endswith("*") else [k]
     return out
@@ -79,7 +93,10 @@ def load():
     lib.hd_version.restype = c_int
     lib.hd_last_error.argtypes = [c_char_p, c_size_t]
     lib.hd_last_error.restype = c_size_t
-    lib.hd_moments_workspace_doubles.restype = c_int64
+    for n, args in SIZE_QUERIES.items():
+        fn = getattr(lib, n)
+        fn.argtypes = args
+        fn.restype = c_int64
     for key, args in SIGNATURES.items():
         names = [key[:-1] + "_f32", key[:-1] + "_f64"] if key.endswith("*") else [key]
         for n in names:

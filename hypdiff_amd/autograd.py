@@ -1,0 +1,233 @@
+"""Training path of the denoisers: torch.autograd.Function wrappers whose forward AND
+backward are HIP kernels of libhypdiff_hip.so (no eager-PyTorch arithmetic on activations).
+
+The reference trains its denoisers with plain autograd over nn.Linear / F.gelu
+(diff.py:113-118 -> models/direction_diffusion.py:335-363; diff_graphset.py:64-75 ->
+ddpm.py:71-85).  Here one Function covers a whole Linear(+GELU)(+residual) stack:
+
+  forward   per layer one MFMA GEMM; bias, exact-erf GELU and the residual add leave the
+            accumulators fused, and the pre-activation z is stored next to the output.
+  backward  per layer  dW = dz^T @ x   (hd_gemm_tn_f32: rows split over workgroups, partial
+                                        tiles summed in fixed order -> bit-reproducible)
+                       db = colsum(dz) (hd_colsum_f32)
+                       g  = dz @ W (+ skip gradient), and dz of the layer below =
+                            g * gelu'(z_below) from the same accumulators (hd_gemm_f32_ex, epi 3)
+
+PyTorch owns memory, the autograd graph, the optimizer and RNG; nothing else.
+"""
+import torch
+
+from . import _lib, ops
+
+GELU, RES, LIN = 1, 2, 0        # layer kinds = epilogue codes of hd_gemm_f32
+
+
+def _ws(n, dtype, device):
+    return torch.empty(max(int(n), 1), dtype=dtype, device=device)
+
+
+def gemm_ex(a, w, bias, resid, aux, c, c2, epi):
+    """hd_gemm_f32_ex on fp32 device tensors; a (M,K), w (N,K); c / c2 may be None."""
+    M, K = a.shape
+    N = w.shape[0]
+    if K % 4 or a.stride(0) % 4 or w.stride(0) % 4 or a.data_ptr() % 16 or w.data_ptr() % 16 or a.stride(1) != 1 \
+            or w.stride(1) != 1:
+        kp = (K + 3) // 4 * 4
+        a, w = ops._pad_k(a, kp), ops._pad_k(w, kp)
+    ref = c if c is not None else c2
+    ev = ops.GEMM_EVENTS
+    if ev is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.call("hd_gemm_f32_ex", ops._p(a), ops._p(w), ops._p(bias), ops._p(resid), ops._p(aux), ops._p(c), ops._p(c2),
+              M, N, a.shape[1], a.stride(0), w.stride(0), ref.stride(0), epi, ops._stream())
+    if ev is not None:
+        e1.record()
+        ev.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)))
+
+
+def gemm_tn(a, b, out=None):
+    """out[P,Q] = a[R,P]^T @ b[R,Q] (weight gradient)."""
+    R, P = a.shape
+    Q = b.shape[1]
+    if P % 4 or Q % 4 or a.stride(0) % 4 or b.stride(0) % 4 or a.data_ptr() % 16 or b.data_ptr() % 16:
+        # odd widths (e.g. the D = 14 latents of config 1): zero-padded copies, result sliced back
+        res = gemm_tn(ops._pad_k(a, (P + 3) // 4 * 4), ops._pad_k(b, (Q + 3) // 4 * 4))[:P, :Q]
+        if out is None:
+            return res.contiguous()
+        out.copy_(res)
+        return out
+    if out is None:
+        out = torch.empty(P, Q, dtype=torch.float32, device=a.device)
+    ws = _ws(_lib.load().hd_gemm_tn_workspace_floats(R, P, Q), torch.float32, a.device)
+    ev = ops.GEMM_EVENTS
+    if ev is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.call("hd_gemm_tn_f32", ops._p(a), ops._p(b), ops._p(out), R, P, Q, a.stride(0), b.stride(0), out.stride(0),
+              ops._p(ws), ops._stream())
+    if ev is not None:
+        e1.record()
+        ev.append((e0, e1, 2.0 * R * P * Q, 4.0 * (R * P + R * Q + P * Q)))
+    return out
+
+
+def transpose(w):
+    out = torch.empty(w.shape[1], w.shape[0], dtype=torch.float32, device=w.device)
+    _lib.call("hd_transpose_f32", ops._p(w), ops._p(out), w.shape[0], w.shape[1], w.stride(0), out.stride(0),
+              ops._stream())
+    return out
+
+
+def colsum(x):
+    M, N = x.shape
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    ws = _ws(_lib.load().hd_colsum_workspace_floats(M, N), torch.float32, x.device)
+    _lib.call("hd_colsum_f32", ops._p(x), ops._p(out), M, N, x.stride(0), ops._p(ws), ops._stream())
+    return out
+
+
+class LinearStack(torch.autograd.Function):
+    """y = stack(x): layer l computes z = x_l W_l^T + b_l and x_{l+1} = z (LIN), gelu(z)
+    (GELU) or x_l + gelu(z) (RES).  `x` is a contiguous fp32 (M, K0) tensor with K0 % 4 == 0;
+    W_0 may be narrower than K0 (the packed, zero-padded cat(x, t) input of the mlp denoiser):
+    it is zero-padded for the GEMM and its gradient is sliced back."""
+
+    @staticmethod
+    def forward(ctx, x, kinds, *params):
+        ops._dev(x)
+        ws_, bs_ = params[0::2], params[1::2]
+        assert len(ws_) == len(kinds) == len(bs_)
+        xs, zs, wpad = [], [], []
+        h = x
+        for l, kind in enumerate(kinds):
+            w = ws_[l].detach()
+            if w.shape[1] != h.shape[1] or w.stride(0) % 4 or w.data_ptr() % 16:
+                w = ops._pad_k(w, h.shape[1])
+            wpad.append(w)
+            out = torch.empty(h.shape[0], w.shape[0], dtype=torch.float32, device=h.device)
+            z = torch.empty_like(out) if kind != LIN else None
+            gemm_ex(h, w, bs_[l].detach(), h if kind == RES else None, None, out, z, kind)
+            xs.append(h)
+            zs.append(z)
+            h = out
+        ctx.kinds = kinds
+        ctx.need_x = x.requires_grad
+        ctx.wshapes = [tuple(w.shape) for w in ws_]
+        ctx.save_for_backward(*xs, *[z for z in zs if z is not None], *wpad)
+        ctx.nz = [z is not None for z in zs]
+        return h
+
+    @staticmethod
+    def backward(ctx, gy):
+        kinds, L = ctx.kinds, len(ctx.kinds)
+        saved = list(ctx.saved_tensors)
+        xs = saved[:L]
+        nzc = sum(ctx.nz)
+        zl = saved[L:L + nzc]
+        ws_ = saved[L + nzc:]
+        zs, it = [], iter(zl)
+        for has in ctx.nz:
+            zs.append(next(it) if has else None)
+        gy = gy.contiguous()
+        grads = [None] * (2 * L)
+        # dz of the top layer
+        top = L - 1
+        if kinds[top] == LIN:
+            dz, g_up = gy, None
+        else:       # stack ending in an activation: dz = gy * gelu'(z) through the same epilogue
+            raise NotImplementedError("LinearStack: the last layer must be linear")
+        for l in range(top, -1, -1):
+            x_l, w = xs[l], ws_[l]
+            dw = gemm_tn(dz, x_l)
+            shp = ctx.wshapes[l]
+            grads[2 * l] = dw if tuple(dw.shape) == shp else dw[:, :shp[1]].contiguous()
+            grads[2 * l + 1] = colsum(dz)
+            if l == 0 and not ctx.need_x:
+                break
+            wt = transpose(w)                                    # (K_l, N_l): contraction over N_l
+            M, Kl = x_l.shape
+            resid = g_up if kinds[l] == RES else None
+            if l == 0:
+                gx = torch.empty(M, Kl, dtype=torch.float32, device=gy.device)
+                gemm_ex(dz, wt, None, resid, None, gx, None, 3)
+                g_up = gx
+                break
+            keep_g = kinds[l - 1] == RES
+            g = torch.empty(M, Kl, dtype=torch.float32, device=gy.device) if keep_g else None
+            dz_below = torch.empty(M, Kl, dtype=torch.float32, device=gy.device)
+            gemm_ex(dz, wt, None, resid, zs[l - 1], g, dz_below, 3)
+            g_up, dz = g, dz_below
+        gx = g_up if ctx.need_x else None
+        return (gx, None, *grads)
+
+
+def linear_stack(x, layers, kinds):
+    """layers: list of nn.Linear; kinds: tuple of GELU/RES/LIN."""
+    params = []
+    for lyr in layers:
+        params += [lyr.weight, lyr.bias]
+    return LinearStack.apply(x, tuple(kinds), *params)
+
+
+class EmbeddingAdd(torch.autograd.Function):
+    """h + table[idx] (ddpm.py:39-41).  Backward: the table gradient is a segment sum of the
+    rows of dL/dh grouped by idx -- an SpMM with the (T x rows) 0/1 selection matrix in CSR
+    (hd_spmm_csr: rows summed in index order, deterministic, no atomics)."""
+
+    @staticmethod
+    def forward(ctx, h, table, idx):
+        if h.is_contiguous():
+            out = h
+            ctx.mark_dirty(h)
+        else:
+            out = h.contiguous()
+        tab = table.detach()
+        _lib.call("hd_embedding_add", ops._p(out), ops._p(tab), ops._p(idx), tab.shape[0], out.shape[0], out.shape[1],
+                  ops._stream())
+        ctx.save_for_backward(idx)
+        ctx.T = tab.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        g = g.contiguous()
+        order = torch.sort(idx, stable=True)
+        coo = torch.stack([order.values, order.indices])
+        csr = ops.csr_from_coo(coo, torch.ones(idx.shape[0], dtype=torch.float32, device=g.device),
+                               (ctx.T, idx.shape[0]))
+        return g, ops.spmm(csr, g), None
+
+
+class MSELoss(torch.autograd.Function):
+    """F.mse_loss(a, b) / (a - b).square().mean() with b a constant target."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ops._dev(a, b)
+        a, b = a.contiguous(), b.detach().to(torch.float32).contiguous()
+        assert a.shape == b.shape and a.dtype == torch.float32
+        d = torch.empty_like(a)
+        ws = _ws(_lib.load().hd_mse_workspace_doubles(), torch.float64, a.device)
+        loss = torch.empty(1, dtype=torch.float32, device=a.device)
+        _lib.call("hd_mse_forward_f32", ops._p(a), ops._p(b), ops._p(d), a.numel(), ops._p(ws), ops._p(loss),
+                  ops._stream())
+        ctx.save_for_backward(d)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        (d,) = ctx.saved_tensors
+        gl = gl.to(torch.float32).reshape(1).contiguous()
+        out = torch.empty_like(d)
+        _lib.call("hd_mse_backward_f32", ops._p(d), ops._p(gl), ops._p(out), d.numel(), ops._stream())
+        return out, None
+
+
+def mse_loss(a, b):
+    return MSELoss.apply(a, b)
+
+
+def wants_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)

@@ -50,12 +50,21 @@ __device__ __forceinline__ float erf_fast(float a) {
     return t > 0.927734375f ? r : q;
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
+// d/dx of the exact-erf GELU: Phi(x) + x * phi(x)
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    return 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
 
-// epi: 0 none, 1 gelu, 2 residual + gelu (ddpm.py:20-22: x0 + gelu(layer(x0)))
+// epi: 0 none, 1 gelu, 2 residual + gelu (ddpm.py:20-22: x0 + gelu(layer(x0)));
+//      with C2 != NULL modes 1 and 2 also store the pre-activation z = acc + bias (training).
+//      3 = input-gradient form: g = acc (+ resid); C = g if C != NULL; C2 = g * gelu'(aux) if
+//      C2 != NULL (the next layer-down's pre-activation gradient, fused into the write-out).
 template <int BNT>
 __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A, const float* __restrict__ W,
                                                      const float* __restrict__ bias,
-                                                     const float* __restrict__ resid, float* __restrict__ C,
+                                                     const float* __restrict__ resid,
+                                                     const float* __restrict__ aux, float* __restrict__ C,
+                                                     float* __restrict__ C2,
                                                      int M, int N, int K, int lda, int ldw, int ldc, int epi,
                                                      int tiles_m, int tiles_n) {
     constexpr int NT = BNT / 64;               // 32-col MFMA tiles per wavefront along N: 2 (BN=128) or 1 (BN=64)
@@ -184,10 +193,18 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A
             for (int r = 0; r < 16; ++r) {
                 const int rm = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (rm < M) {
+                    const size_t o = (size_t)rm * ldc + cn;
                     float v = acc[i][j][r] + bv;
-                    if (epi == 1) v = gelu_erf(v);
-                    else if (epi == 2) v = resid[(size_t)rm * ldc + cn] + gelu_erf(v);
-                    C[(size_t)rm * ldc + cn] = v;
+                    if (epi == 3) {
+                        if (resid) v += resid[o];
+                        if (C) C[o] = v;
+                        if (C2) C2[o] = v * gelu_erf_grad(aux[o]);
+                    } else {
+                        if (epi != 0 && C2) C2[o] = v;
+                        if (epi == 1) v = gelu_erf(v);
+                        else if (epi == 2) v = resid[o] + gelu_erf(v);
+                        C[o] = v;
+                    }
                 }
             }
         }
@@ -233,18 +250,19 @@ __global__ __launch_bounds__(256) void gemm_f64_valu(const double* __restrict__ 
 
 }  // namespace
 
-extern "C" int hd_gemm_f32(const void* A, const void* W, const void* bias, const void* resid, void* C,
-                           int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int epi,
-                           void* st) {
+extern "C" int hd_gemm_f32_ex(const void* A, const void* W, const void* bias, const void* resid, const void* aux,
+                              void* C, void* C2, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                              int64_t ldc, int epi, void* st) {
     HD_REQUIRE(M >= 0 && N >= 1 && K >= 1, "hd_gemm_f32: bad shape M=%lld N=%lld K=%lld", (long long)M,
                (long long)N, (long long)K);
     if (M == 0) return HD_OK;
-    HD_REQUIRE(A && W && C, "hd_gemm_f32: null pointer");
+    HD_REQUIRE(A && W && (C || (epi == 3 && C2)), "hd_gemm_f32: null pointer");
     HD_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), "hd_gemm_f32: size exceeds int32");
     HD_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && is_aligned16(A) && is_aligned16(W),
                "hd_gemm_f32: K, lda, ldw must be multiples of 4 and A, W 16-byte aligned (pad with zeros)");
     HD_REQUIRE(lda >= K && ldw >= K && ldc >= N, "hd_gemm_f32: leading dimension too small");
-    HD_REQUIRE(epi >= 0 && epi <= 2 && (epi != 2 || resid), "hd_gemm_f32: bad epilogue / missing residual");
+    HD_REQUIRE(epi >= 0 && epi <= 3 && (epi != 2 || resid), "hd_gemm_f32: bad epilogue / missing residual");
+    HD_REQUIRE(epi != 3 || !C2 || aux, "hd_gemm_f32: gradient epilogue needs the saved pre-activation");
     const dim3 blk(256);
     // Tile width and residency (workgroups per CU, capped by requesting unused dynamic LDS).
     // Measured on MI355X over the denoiser / HypLinear shapes (M = 15 777, N,K in 512..900):
@@ -265,15 +283,22 @@ extern "C" int hd_gemm_f32(const void* A, const void* W, const void* bias, const
     if (best_w == 64) {
         const int tiles_n = (int)((N + 63) / 64);
         gemm_f32_mfma<64><<<dim3((unsigned)(tiles_m * tiles_n)), blk, dyn, (hipStream_t)st>>>(
-            (const float*)A, (const float*)W, (const float*)bias, (const float*)resid, (float*)C, (int)M, (int)N,
-            (int)K, (int)lda, (int)ldw, (int)ldc, epi, tiles_m, tiles_n);
+            (const float*)A, (const float*)W, (const float*)bias, (const float*)resid, (const float*)aux, (float*)C,
+            (float*)C2, (int)M, (int)N, (int)K, (int)lda, (int)ldw, (int)ldc, epi, tiles_m, tiles_n);
     } else {
         const int tiles_n = (int)((N + 127) / 128);
         gemm_f32_mfma<128><<<dim3((unsigned)(tiles_m * tiles_n)), blk, dyn, (hipStream_t)st>>>(
-            (const float*)A, (const float*)W, (const float*)bias, (const float*)resid, (float*)C, (int)M, (int)N,
-            (int)K, (int)lda, (int)ldw, (int)ldc, epi, tiles_m, tiles_n);
+            (const float*)A, (const float*)W, (const float*)bias, (const float*)resid, (const float*)aux, (float*)C,
+            (float*)C2, (int)M, (int)N, (int)K, (int)lda, (int)ldw, (int)ldc, epi, tiles_m, tiles_n);
     }
     return check_launch("hd_gemm_f32");
+}
+
+extern "C" int hd_gemm_f32(const void* A, const void* W, const void* bias, const void* resid, void* C,
+                           int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int epi,
+                           void* st) {
+    HD_REQUIRE(epi >= 0 && epi <= 2, "hd_gemm_f32: bad epilogue");
+    return hd_gemm_f32_ex(A, W, bias, resid, nullptr, C, nullptr, M, N, K, lda, ldw, ldc, epi, st);
 }
 
 extern "C" int hd_gemm_f64(const void* A, const void* W, const void* bias, void* C, int64_t M, int64_t N,

@@ -1,0 +1,302 @@
+// Backward-pass kernels of the denoiser training step (models/direction_diffusion.py:335-363,
+// ddpm.py:71-85 followed by loss.backward() in diff.py:113-118 / diff_graphset.py:64-75).
+//
+//  * gemm_tn_f32_mfma: weight gradients dW[P,Q] = sum_r A[r,P] * B[r,Q] (A = dZ, B = layer
+//    input).  The reduction runs over the ROW index of both operands (tens of thousands of
+//    latent rows) and the output is small, so the rows are split over gridDim.y and the
+//    partial tiles are summed in slice order by reduce_slices (fixed shape -> bit-reproducible,
+//    no atomics).  Exact-f32 matrix cores as in gemm.hip; slabs of 32 rows are staged in LDS in
+//    their natural [r][p] layout: the MFMA operand of lane (i, kk) is sA[2s+kk][i], i.e. 32
+//    consecutive floats per half-wave (conflict-free ds_read_b32; at 64 cycles per
+//    v_mfma_f32_32x32x2_f32 the LDS reads are nowhere near the critical path).
+//  * transpose_f32: W -> W^T for the input-gradient GEMM (weights only: < 1 M elements).
+//  * colsum_f32: bias gradients, two-stage column sums.
+//  * mse kernels: F.mse_loss forward (difference + sum of squares) and its gradient.
+#include "hd_common.cuh"
+#include "../../include/hypdiff.h"
+
+using namespace hd;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TP = 128, TQ = 64, TR = 32;
+
+__global__ __launch_bounds__(256) void gemm_tn_f32_mfma(const float* __restrict__ A, const float* __restrict__ B,
+                                                        float* __restrict__ C, int R, int P, int Q, int lda, int ldb,
+                                                        int ldc, int chunk, int tiles_q, size_t slice_stride) {
+    __shared__ __attribute__((aligned(16))) float sA[TR * TP];
+    __shared__ __attribute__((aligned(16))) float sB[TR * TQ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tp = blockIdx.x / tiles_q, tq = blockIdx.x - tp * tiles_q;
+    const int p0 = tp * TP, q0 = tq * TQ;
+    const int r_begin = blockIdx.y * chunk;
+    const int r_end = r_begin + chunk < R ? r_begin + chunk : R;
+
+    // staging: A slab 32 x 128 -> 4 float4 per thread; B slab 32 x 64 -> 2 float4 per thread
+    const int arow = tid >> 5, acol = (tid & 31) * 4;
+    const int brow = tid >> 4, bcol = (tid & 15) * 4;
+    const bool a_in = p0 + acol < P, b_in = q0 + bcol < Q;      // P, Q multiples of 4
+    const float* pa = A + (a_in ? p0 + acol : 0);
+    const float* pb = B + (b_in ? q0 + bcol : 0);
+    float4 ra[4], rb[2];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+#define HD_TN_LOAD(r0)                                                                       \
+    {                                                                                        \
+        _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                      \
+            const int r = (r0) + arow + 8 * p;                                               \
+            const int rc = r < r_end ? r : r_end - 1;                                        \
+            const float4 v = *reinterpret_cast<const float4*>(pa + (size_t)rc * lda);        \
+            ra[p] = (r < r_end && a_in) ? v : zero4;                                         \
+        }                                                                                    \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                      \
+            const int r = (r0) + brow + 16 * p;                                              \
+            const int rc = r < r_end ? r : r_end - 1;                                        \
+            const float4 v = *reinterpret_cast<const float4*>(pb + (size_t)rc * ldb);        \
+            rb[p] = (r < r_end && b_in) ? v : zero4;                                         \
+        }                                                                                    \
+    }
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const int fi = lane & 31, fh = lane >> 5;
+    if (r_begin < r_end) {
+        HD_TN_LOAD(r_begin)
+        for (int r0 = r_begin; r0 < r_end; r0 += TR) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(&sA[(arow + 8 * p) * TP + acol]) = ra[p];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) *reinterpret_cast<float4*>(&sB[(brow + 16 * p) * TQ + bcol]) = rb[p];
+            __syncthreads();
+            if (r0 + TR < r_end) HD_TN_LOAD(r0 + TR)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < TR / 2; ++s) {
+                const int m = 2 * s + fh;
+                const float b = sB[m * TQ + wc * 32 + fi];
+                const float a0 = sA[m * TP + wr * 64 + fi];
+                const float a1 = sA[m * TP + wr * 64 + 32 + fi];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+#undef HD_TN_LOAD
+
+    float* out = C + (size_t)blockIdx.y * slice_stride;
+    const int cq = q0 + wc * 32 + fi;
+    if (cq < Q) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rp = p0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (rp < P) out[(size_t)rp * ldc + cq] = acc[i][r];
+            }
+    }
+}
+
+// out[i] = sum_s ws[s * stride + i], s ascending (fixed order)
+__global__ __launch_bounds__(256) void reduce_slices(const float* __restrict__ ws, int S, size_t stride, size_t count,
+                                                     float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        float s = ws[i];
+        for (int k = 1; k < S; ++k) s += ws[(size_t)k * stride + i];
+        out[i] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_f32(const float* __restrict__ in, float* __restrict__ out, int rows,
+                                                     int cols, int ld_in, int ld_out) {
+    __shared__ float tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int r = ty; r < 64; r += 4)
+        if (r0 + r < rows && c0 + tx < cols) tile[r][tx] = in[(size_t)(r0 + r) * ld_in + c0 + tx];
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4)
+        if (c0 + c < cols && r0 + tx < rows) out[(size_t)(c0 + c) * ld_out + r0 + tx] = tile[tx][c];
+}
+
+// partial column sums: block = 64 columns x 4 row lanes, gridDim.y row chunks -> ws[chunk][N]
+__global__ __launch_bounds__(256) void colsum_partial(const float* __restrict__ x, int M, int N, int ld, int chunk,
+                                                      float* __restrict__ ws) {
+    __shared__ float part[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const int r_begin = blockIdx.y * chunk, r_end = r_begin + chunk < M ? r_begin + chunk : M;
+    float s = 0.f;
+    if (c < N)
+        for (int r = r_begin + ty; r < r_end; r += 4) s += x[(size_t)r * ld + c];
+    part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < N) ws[(size_t)blockIdx.y * N + c] = (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
+}
+
+// d = a - b and per-block partial sums of d^2 (fp64)
+__global__ __launch_bounds__(256) void mse_diff(const float* __restrict__ a, const float* __restrict__ b,
+                                                float* __restrict__ d, size_t count, double* __restrict__ partial) {
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        const float v = a[i] - b[i];
+        d[i] = v;
+        s += (double)v * (double)v;
+    }
+    s = group_sum<64>(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+__global__ __launch_bounds__(256) void mse_final(const double* __restrict__ partial, int n, double count,
+                                                 float* __restrict__ loss) {
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    s = group_sum<64>(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (float)(((sm[0] + sm[1]) + (sm[2] + sm[3])) / count);
+}
+
+// out = d * (factor * g[0])
+__global__ __launch_bounds__(256) void scale_by_dev(const float* __restrict__ d, const float* __restrict__ g,
+                                                    float factor, float* __restrict__ out, size_t count) {
+    const float f = factor * g[0];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) out[i] = d[i] * f;
+}
+
+inline int pick_splits(int64_t R, int64_t tiles) {
+    // enough workgroups for 4 per CU on 256 CUs, each with at least 8 slabs of 32 rows
+    int64_t s = (1024 + tiles - 1) / tiles;
+    const int64_t smax = (R + 255) / 256;
+    if (s > smax) s = smax;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return (int)s;
+}
+
+constexpr int kMsePartials = 1024;
+
+}  // namespace
+
+extern "C" int64_t hd_gemm_tn_workspace_floats(int64_t R, int64_t P, int64_t Q) {
+    if (R < 1 || P < 1 || Q < 1) return 0;
+    const int64_t tiles = ((P + TP - 1) / TP) * ((Q + TQ - 1) / TQ);
+    const int s = pick_splits(R, tiles);
+    return s > 1 ? (int64_t)s * P * Q : 0;
+}
+
+extern "C" int hd_gemm_tn_f32(const void* A, const void* B, void* C, int64_t R, int64_t P, int64_t Q, int64_t lda,
+                              int64_t ldb, int64_t ldc, void* workspace, void* st) {
+    HD_REQUIRE(R >= 0 && P >= 1 && Q >= 1, "hd_gemm_tn_f32: bad shape R=%lld P=%lld Q=%lld", (long long)R,
+               (long long)P, (long long)Q);
+    HD_REQUIRE(A && B && C, "hd_gemm_tn_f32: null pointer");
+    HD_REQUIRE(R < (1LL << 31) && P < (1LL << 31) && Q < (1LL << 31), "hd_gemm_tn_f32: size exceeds int32");
+    HD_REQUIRE(P % 4 == 0 && Q % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && is_aligned16(A) && is_aligned16(B),
+               "hd_gemm_tn_f32: P, Q, lda, ldb must be multiples of 4 and A, B 16-byte aligned (pad with zeros)");
+    HD_REQUIRE(lda >= P && ldb >= Q && ldc >= Q, "hd_gemm_tn_f32: leading dimension too small");
+    hipStream_t s = (hipStream_t)st;
+    if (R == 0) {
+        HD_REQUIRE(ldc == Q, "hd_gemm_tn_f32: empty reduction needs a contiguous output");
+        if (hipMemsetAsync(C, 0, (size_t)P * Q * sizeof(float), s) != hipSuccess) return check_launch("hd_gemm_tn_f32");
+        return HD_OK;
+    }
+    const int tiles_p = (int)((P + TP - 1) / TP), tiles_q = (int)((Q + TQ - 1) / TQ);
+    const int splits = pick_splits(R, (int64_t)tiles_p * tiles_q);
+    int chunk = (int)((R + splits - 1) / splits);
+    chunk = (chunk + TR - 1) / TR * TR;
+    const int nsl = (int)((R + chunk - 1) / chunk);
+    if (nsl > 1) {
+        HD_REQUIRE(workspace, "hd_gemm_tn_f32: workspace of hd_gemm_tn_workspace_floats() floats required");
+        HD_REQUIRE(ldc == Q, "hd_gemm_tn_f32: split reduction needs a contiguous output (ldc == Q)");
+        gemm_tn_f32_mfma<<<dim3((unsigned)(tiles_p * tiles_q), (unsigned)nsl), 256, 0, s>>>(
+            (const float*)A, (const float*)B, (float*)workspace, (int)R, (int)P, (int)Q, (int)lda, (int)ldb, (int)Q, chunk,
+            tiles_q, (size_t)P * Q);
+        const size_t count = (size_t)P * Q;
+        int blocks = (int)((count + 255) / 256);
+        blocks = blocks < 2048 ? blocks : 2048;
+        reduce_slices<<<blocks, 256, 0, s>>>((const float*)workspace, nsl, count, count, (float*)C);
+    } else {
+        gemm_tn_f32_mfma<<<dim3((unsigned)(tiles_p * tiles_q), 1u), 256, 0, s>>>(
+            (const float*)A, (const float*)B, (float*)C, (int)R, (int)P, (int)Q, (int)lda, (int)ldb, (int)ldc, chunk,
+            tiles_q, 0);
+    }
+    return check_launch("hd_gemm_tn_f32");
+}
+
+extern "C" int hd_transpose_f32(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out,
+                                void* st) {
+    HD_REQUIRE(rows >= 0 && cols >= 0 && ld_in >= cols && ld_out >= rows, "hd_transpose_f32: bad shape");
+    if (rows == 0 || cols == 0) return HD_OK;
+    HD_REQUIRE(in && out && in != out, "hd_transpose_f32: null or aliased pointer");
+    HD_REQUIRE(rows < (1LL << 31) && cols < (1LL << 31), "hd_transpose_f32: size exceeds int32");
+    const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
+    HD_REQUIRE(grid.y < 65536, "hd_transpose_f32: too many row tiles");
+    transpose_f32<<<grid, 256, 0, (hipStream_t)st>>>((const float*)in, (float*)out, (int)rows, (int)cols, (int)ld_in,
+                                                      (int)ld_out);
+    return check_launch("hd_transpose_f32");
+}
+
+extern "C" int64_t hd_colsum_workspace_floats(int64_t M, int64_t N) {
+    if (M < 1 || N < 1) return 0;
+    int64_t chunks = (M + 255) / 256;
+    chunks = chunks < 64 ? chunks : 64;
+    return chunks * N;
+}
+
+extern "C" int hd_colsum_f32(const void* x, void* out, int64_t M, int64_t N, int64_t ld, void* workspace, void* st) {
+    HD_REQUIRE(M >= 0 && N >= 1 && ld >= N, "hd_colsum_f32: bad shape");
+    HD_REQUIRE(out, "hd_colsum_f32: null pointer");
+    hipStream_t s = (hipStream_t)st;
+    if (M == 0) {
+        if (hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s) != hipSuccess) return check_launch("hd_colsum_f32");
+        return HD_OK;
+    }
+    HD_REQUIRE(x && workspace, "hd_colsum_f32: null pointer");
+    HD_REQUIRE(M < (1LL << 31) && N < (1LL << 31), "hd_colsum_f32: size exceeds int32");
+    int64_t chunks = (M + 255) / 256;
+    chunks = chunks < 64 ? chunks : 64;
+    const int chunk = (int)((M + chunks - 1) / chunks);
+    const int nch = (int)((M + chunk - 1) / chunk);
+    colsum_partial<<<dim3((unsigned)((N + 63) / 64), (unsigned)nch), 256, 0, s>>>((const float*)x, (int)M, (int)N, (int)ld,
+                                                                                 chunk, (float*)workspace);
+    int blocks = (int)((N + 255) / 256);
+    reduce_slices<<<blocks, 256, 0, s>>>((const float*)workspace, nch, (size_t)N, (size_t)N, (float*)out);
+    return check_launch("hd_colsum_f32");
+}
+
+extern "C" int64_t hd_mse_workspace_doubles(void) { return kMsePartials; }
+
+extern "C" int hd_mse_forward_f32(const void* a, const void* b, void* diff, int64_t count, void* workspace, void* loss,
+                                  void* st) {
+    HD_REQUIRE(count >= 1, "hd_mse_forward_f32: empty input");
+    HD_REQUIRE(a && b && diff && workspace && loss, "hd_mse_forward_f32: null pointer");
+    int64_t blocks = (count + 255) / 256;
+    blocks = blocks < kMsePartials ? blocks : kMsePartials;
+    hipStream_t s = (hipStream_t)st;
+    mse_diff<<<(unsigned)blocks, 256, 0, s>>>((const float*)a, (const float*)b, (float*)diff, (size_t)count,
+                                              (double*)workspace);
+    mse_final<<<1, 256, 0, s>>>((const double*)workspace, (int)blocks, (double)count, (float*)loss);
+    return check_launch("hd_mse_forward_f32");
+}
+
+extern "C" int hd_mse_backward_f32(const void* diff, const void* grad_loss, void* grad_out, int64_t count, void* st) {
+    HD_REQUIRE(count >= 1, "hd_mse_backward_f32: empty input");
+    HD_REQUIRE(diff && grad_loss && grad_out, "hd_mse_backward_f32: null pointer");
+    int64_t blocks = (count + 255) / 256;
+    blocks = blocks < 4096 ? blocks : 4096;
+    scale_by_dev<<<(unsigned)blocks, 256, 0, (hipStream_t)st>>>((const float*)diff, (const float*)grad_loss,
+                                                                (float)(2.0 / (double)count), (float*)grad_out,
+                                                                (size_t)count);
+    return check_launch("hd_mse_backward_f32");
+}

@@ -10,6 +10,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import autograd as hag
 from . import ops
 
 
@@ -24,9 +25,15 @@ class MLP(nn.Module):
         self.gelu = nn.GELU()
 
     def forward(self, x):
-        ops._dev(x); ops._no_grad(x, self.layers[0].weight)
+        ops._dev(x)
         x = x.to(torch.float32).contiguous()
         last = len(self.layers) - 1
+        if hag.wants_grad(x, *self.parameters()):
+            # training (diff_graphset.py:64-75): HIP forward + backward, see hypdiff_amd/autograd.py
+            if x.shape[1] % 4:
+                x = ops._pad_k(x, (x.shape[1] + 3) // 4 * 4)
+            kinds = (hag.GELU,) + (hag.RES,) * (last - 1) + (hag.LIN,)
+            return hag.linear_stack(x, list(self.layers), kinds)
         for idx, layer in enumerate(self.layers):
             w, b = layer.weight.detach(), layer.bias.detach()
             if idx == 0:
@@ -49,8 +56,10 @@ class Backbone(nn.Module):
 
     def forward(self, x, idx):
         h = self.linear_model1(x)
-        tab = self.embedding_layer.weight.detach()
         idx = idx.to(device=h.device, dtype=torch.int64).contiguous()
+        if hag.wants_grad(h, self.embedding_layer.weight):
+            return self.linear_model2(hag.EmbeddingAdd.apply(h, self.embedding_layer.weight, idx))
+        tab = self.embedding_layer.weight.detach()
         ops._lib.call("hd_embedding_add", ops._p(h), ops._p(tab), ops._p(idx), tab.shape[0], h.shape[0], h.shape[1],
                       ops._stream())
         return self.linear_model2(h)
@@ -83,8 +92,8 @@ class Model(nn.Module):
         """ddpm.py:71-85 (forward value; `idx` / `epsilon` optionally inject the draws)"""
         output, epsilon, alpha_bar = self.forward(x, idx=idx, get_target=True, epsilon=epsilon, _train=True)
         if target == 'pred_noise':
-            return (output - epsilon).square().mean()
-        return (output - x).square().mean()
+            return hag.mse_loss(output, epsilon)
+        return hag.mse_loss(output, x)
 
     def forward(self, x, idx=None, get_target=False, restrict=False, epsilon=None, _train=False):
         """ddpm.py:87-111.  idx None (or `_train`): training-time noising at random / given

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import autograd as hag
 from .. import ops
 from ..manifolds.poincare import PoincareBall
 
@@ -58,7 +59,7 @@ class mlp(nn.Module):
         return self._w1_cache[1]
 
     def forward(self, x, t):
-        ops._dev(x); ops._no_grad(x, self.fc1.weight)
+        ops._dev(x); ops._no_grad(x)
         x = x.contiguous()
         n, d = x.shape
         ld = (d + 1 + 3) // 4 * 4
@@ -73,6 +74,10 @@ class mlp(nn.Module):
             kind, tp, ts = 2, None, float(t)
         ops._lib.call("hd_mlp_pack_input", ops._p(x), 1 if x.dtype == torch.float64 else 0, ops._p(tp), kind, ts,
                       ops._p(h), n, d, ld, ops._stream())
+        if hag.wants_grad(*self.parameters()):
+            # training (diff.py:113-118): forward and backward on HIP kernels, autograd only links them
+            return hag.linear_stack(h, [self.fc1, self.fc2, self.fc3, self.fc4, self.fc5],
+                                    (hag.GELU, hag.GELU, hag.GELU, hag.GELU, hag.LIN))
         h = ops.gemm(h, self._w1(ld), self.fc1.bias.detach(), epi=1)
         h = ops.gemm(h, self.fc2.weight.detach(), self.fc2.bias.detach(), epi=1)
         h = ops.gemm(h, self.fc3.weight.detach(), self.fc3.bias.detach(), epi=1)
@@ -287,7 +292,8 @@ class diffusion(nn.Module):
         return ops.map_at("hd_pb_expmap_at", centres, lab, ret, 1.0)
 
     def forward(self, x, adj, labels, u0, restrict=True, graphset=False, t=None, noise=None):
-        """:335-363 training loss (forward value only in this round; no autograd graph).
+        """:335-363 training loss; differentiable w.r.t. the denoiser parameters
+        (loss.backward() runs hd_gemm_tn_f32 / hd_gemm_f32_ex kernels, hypdiff_amd/autograd.py).
         `t` / `noise` optionally inject the draws."""
         if not graphset:
             raise NotImplementedError("gcndec denoiser not built; use graphset=True")
@@ -304,4 +310,4 @@ class diffusion(nn.Module):
         xt = self.q_sample(x_start=x_start, t=t, direction=direction, noise=noise, labels=labels, u0=u0,
                            restrict=True)
         out = self.mlp(xt, t / self.num_timesteps)
-        return F.mse_loss(out, x_start.to(torch.float32))
+        return hag.mse_loss(out, x_start.to(torch.float32))

@@ -140,6 +140,38 @@ HD_DECL2(hd_hb_agg, const int32_t* rowptr, const int32_t* col, const void* val, 
  * (ddpm.py:20-22).  K, lda, ldw multiples of 4, A/W 16-byte aligned (pad with zeros). */
 int hd_gemm_f32(const void* A, const void* W, const void* bias, const void* resid, void* C, int64_t M,
                 int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int epi, void* stream);
+/* Training form of hd_gemm_f32 (loss.backward() of diff.py:113-118 / diff_graphset.py:64-75 over
+ * the Linear+GELU stacks of models/direction_diffusion.py:56-69 and ddpm.py:17-27).
+ * epi 1 / 2 with C2 != NULL also store the pre-activation z = A W^T + bias into C2 (saved for
+ * the backward pass).  epi 3 is the input-gradient form: g = A W^T (+ resid), A = dL/dz of a
+ * layer and W its TRANSPOSED weight (hd_transpose_f32); C = g when C != NULL, and
+ * C2 = g * gelu'(aux) when C2 != NULL (aux = saved pre-activation of the layer below), so the
+ * next layer's dL/dz leaves the accumulators without a separate elementwise pass.  resid,
+ * aux, C, C2 all have leading dimension ldc. */
+int hd_gemm_f32_ex(const void* A, const void* W, const void* bias, const void* resid, const void* aux, void* C,
+                   void* C2, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int epi,
+                   void* stream);
+/* Weight gradient dW[P,Q] = A[R,P]^T @ B[R,Q] (A = dL/dz, B = layer input; autograd of
+ * F.linear, models/direction_diffusion.py:56-69).  The R rows are split over workgroups and
+ * the partial tiles summed in slice order (bit-reproducible).  P, Q, lda, ldb multiples of 4;
+ * workspace holds hd_gemm_tn_workspace_floats(R,P,Q) floats (0 = none needed). */
+int64_t hd_gemm_tn_workspace_floats(int64_t R, int64_t P, int64_t Q);
+int hd_gemm_tn_f32(const void* A, const void* B, void* C, int64_t R, int64_t P, int64_t Q, int64_t lda, int64_t ldb,
+                   int64_t ldc, void* workspace, void* stream);
+/* out[cols, rows] = in[rows, cols]^T */
+int hd_transpose_f32(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out,
+                     void* stream);
+/* bias gradient: out[n] = sum_m x[m, n]; workspace of hd_colsum_workspace_floats(M,N) floats */
+int64_t hd_colsum_workspace_floats(int64_t M, int64_t N);
+int hd_colsum_f32(const void* x, void* out, int64_t M, int64_t N, int64_t ld, void* workspace, void* stream);
+/* F.mse_loss(a, b) (models/direction_diffusion.py:362; ddpm.py:83-85 `.square().mean()`):
+ * diff = a - b (kept for the backward pass), loss[0] = mean(diff^2) (fp64 accumulation);
+ * workspace of hd_mse_workspace_doubles() doubles.  Backward: grad_out = diff * 2/count *
+ * grad_loss[0] (grad_loss is a DEVICE scalar: no host read-back inside loss.backward()). */
+int64_t hd_mse_workspace_doubles(void);
+int hd_mse_forward_f32(const void* a, const void* b, void* diff, int64_t count, void* workspace, void* loss,
+                       void* stream);
+int hd_mse_backward_f32(const void* diff, const void* grad_loss, void* grad_out, int64_t count, void* stream);
 /* double-precision x @ W^T (+bias) for fp64 HypLinear */
 int hd_gemm_f64(const void* A, const void* W, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
                 int64_t lda, int64_t ldw, int64_t ldc, void* stream);

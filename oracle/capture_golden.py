@@ -390,6 +390,60 @@ def capture_ddpm(out_dir):
     print("ddpm", len(store), "arrays")
 
 
+def capture_train(out_dir):
+    """Gradients of the two denoiser training losses, taken by the reference's own autograd:
+    diffusion.forward (models/direction_diffusion.py:335-363, mlp denoiser) as diff.py:113-118
+    runs it, and ddpm.Model.loss_fn (ddpm.py:71-85) as diff_graphset.py:64-75 runs it.  Inputs
+    are the cases of diffusion.npz / ddpm.npz (same seeds), so only losses and gradients are
+    stored here."""
+    import models.direction_diffusion as dd
+    import ddpm as rddpm
+    store = {}
+    n, dim, k = 24, 16, 3
+    torch.manual_seed(1432)
+    diff = dd.diffusion(types.SimpleNamespace(r=2.0, t=1.0), dim).train()
+    load_mlp(diff, dim)
+    case = gi.diffusion_case(n, dim, k)
+    rs = case["rs"]
+    labels, u0 = case["labels"], T(case["u0"])
+    t = T(rs.randint(0, 200, size=n).astype(np.int64))
+    store["diffusion/t"] = N(t)
+    xin = T(case["x"], torch.float32).clone()
+    nz = T(case["noise"], torch.float64)
+    with injected(randint=lambda *a, **k: t.clone(), randn_like=lambda *a, **k: nz.clone()):
+        loss = diff(xin, 1, labels, u0, restrict=True, graphset=True)
+    loss.backward()
+    store["diffusion/loss"] = N(loss)
+    for i in range(1, 6):
+        fc = getattr(diff.mlp, f"fc{i}")
+        g = N(fc.weight.grad)
+        if g.size > 50000:      # big hidden layers: strided sample + row / column sums keep the fixture small
+            store[f"diffusion/grad/fc{i}.weight/sample_7_5"] = g[::7, ::5].copy()
+            store[f"diffusion/grad/fc{i}.weight/rowsum"] = g.astype(np.float64).sum(1)
+            store[f"diffusion/grad/fc{i}.weight/colsum"] = g.astype(np.float64).sum(0)
+        else:
+            store[f"diffusion/grad/fc{i}.weight"] = g
+        store[f"diffusion/grad/fc{i}.bias"] = N(fc.bias.grad)
+
+    rs = np.random.RandomState(1432)
+    B, D, Hd, L, Tn = 10, 64, 64, 3, 1000
+    torch.manual_seed(1432)
+    model = rddpm.Model(D, Hd, L, Tn, 1e-4, 0.02).train()
+    x = T(rs.standard_normal((B, D)).astype(np.float32))
+    eps = T(rs.standard_normal((B, D)).astype(np.float32))
+    idx = T(rs.randint(0, Tn, size=B).astype(np.int64))
+    idx[3] = idx[7]                      # a repeated step: two rows add into one embedding row
+    store["ddpm/idx"] = N(idx)
+    with injected(randint=lambda *a, **k: idx.clone(), randn_like=lambda *a, **k: eps.clone()):
+        loss = model.loss_fn(x)
+    loss.backward()
+    store["ddpm/loss"] = N(loss)
+    for name, p_ in model.named_parameters():
+        store["ddpm/grad/" + name] = N(p_.grad)
+    np.savez_compressed(os.path.join(out_dir, "train.npz"), **store)
+    print("train", len(store), "arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
@@ -409,6 +463,8 @@ def main():
         capture_diffusionset(out)
     if a.only in ("", "ddpm"):
         capture_ddpm(out)
+    if a.only in ("", "train"):
+        capture_train(out)
 
 
 if __name__ == "__main__":
