@@ -162,6 +162,11 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int fi = lane & 31, fh = lane >> 5;
+    // A wavefront whose 64 x (BNT/2) quadrant lies entirely beyond M or N (ragged last block
+    // row / column: N = 900 fills 14 column blocks and 4 columns of a 15th) skips its MFMAs --
+    // wave-uniform, and the matrix pipe it would have occupied serves the other resident
+    // workgroups of the SIMD.  It still takes part in the staging and the barriers.
+    const bool wave_live = (m0 + wr * 64 < M) && (n0 + wc * (BNT / 2) < N);
     const int nk = (K + BK - 1) / BK;
     // Software pipeline: while slab t is multiplied out of LDS the loads of slab t+1 are in
     // flight into registers.  The sched_barrier keeps the loads where they are written: hipcc
@@ -169,6 +174,18 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A
     // iteration then waits out the full memory latency.  (A second register set / prefetch
     // distance 2 was measured: no gain, 32 more VGPRs.)
     HD_GLOAD(ra, rw, kinA, 0)
+    if (!wave_live) {
+        // staging-only copy of the loop (same barrier count).  A separate loop rather than a
+        // predicate around HD_COMPUTE: conditionally updated accumulators leave the AGPRs and
+        // cost the live path 30+ VGPRs, i.e. one resident workgroup per CU.
+        for (int kt = 0; kt < nk; ++kt) {
+            HD_SSTORE(ra, rw, kinA)
+            __syncthreads();
+            HD_GLOAD(ra, rw, kinA, (kt + 1) * BK)
+            __syncthreads();
+        }
+        return;
+    }
     for (int kt = 0; kt < nk; ++kt) {
         HD_SSTORE(ra, rw, kinA)
         __syncthreads();

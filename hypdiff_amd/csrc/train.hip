@@ -3,8 +3,8 @@
 //
 //  * gemm_tn_f32_mfma: weight gradients dW[P,Q] = sum_r A[r,P] * B[r,Q] (A = dZ, B = layer
 //    input).  The reduction runs over the ROW index of both operands (tens of thousands of
-//    latent rows) and the output is small, so the rows are split over gridDim.y and the
-//    partial tiles are summed in slice order by reduce_slices (fixed shape -> bit-reproducible,
+//    latent rows) and the output is small, so the rows are split into slices (one workgroup per
+//    slice and output tile) whose partial tiles reduce_slices sums in slice order (bit-reproducible,
 //    no atomics).  Exact-f32 matrix cores as in gemm.hip; slabs of 32 rows are staged in LDS in
 //    their natural [r][p] layout: the MFMA operand of lane (i, kk) is sA[2s+kk][i], i.e. 32
 //    consecutive floats per half-wave (conflict-free ds_read_b32; at 64 cycles per
@@ -21,85 +21,131 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int TP = 128, TQ = 64, TR = 32;
+constexpr int TP = 128, TQ = 128, TR = 32;
 
+// Workgroup -> (row slice, output tile).  The hardware deals consecutive workgroup ids
+// round-robin over the 8 XCDs; every XCD gets a contiguous run of logical indices, i.e. whole
+// row slices: all output tiles of a slice then run on ONE XCD and stream the same rows of A
+// and B in step, so each operand row leaves HBM once and is shared through that XCD's L2
+// (without this every XCD pulled all of A and B: 1.3 GB of fabric traffic per call, 39 TF).
 __global__ __launch_bounds__(256) void gemm_tn_f32_mfma(const float* __restrict__ A, const float* __restrict__ B,
                                                         float* __restrict__ C, int R, int P, int Q, int lda, int ldb,
-                                                        int ldc, int chunk, int tiles_q, size_t slice_stride) {
+                                                        int ldc, int chunk, int tiles_q, int tiles, int total,
+                                                        size_t slice_stride) {
     __shared__ __attribute__((aligned(16))) float sA[TR * TP];
     __shared__ __attribute__((aligned(16))) float sB[TR * TQ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int tp = blockIdx.x / tiles_q, tq = blockIdx.x - tp * tiles_q;
+    int logical = blockIdx.x;
+    {
+        const int q = total >> 3, r = total & 7, xcd = logical & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (logical >> 3);
+    }
+    const int slice = logical / tiles, tile = logical - slice * tiles;
+    const int tp = tile / tiles_q, tq = tile - tp * tiles_q;
     const int p0 = tp * TP, q0 = tq * TQ;
-    const int r_begin = blockIdx.y * chunk;
+    const int r_begin = slice * chunk;
     const int r_end = r_begin + chunk < R ? r_begin + chunk : R;
 
-    // staging: A slab 32 x 128 -> 4 float4 per thread; B slab 32 x 64 -> 2 float4 per thread
-    const int arow = tid >> 5, acol = (tid & 31) * 4;
-    const int brow = tid >> 4, bcol = (tid & 15) * 4;
-    const bool a_in = p0 + acol < P, b_in = q0 + bcol < Q;      // P, Q multiples of 4
-    const float* pa = A + (a_in ? p0 + acol : 0);
-    const float* pb = B + (b_in ? q0 + bcol : 0);
-    float4 ra[4], rb[2];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // staging: each slab is 32 rows x 128 floats per operand -> 4 float4 per thread and operand
+    const int srow = tid >> 5, scol = (tid & 31) * 4;
+    const bool a_in = p0 + scol < P, b_in = q0 + scol < Q;      // P, Q multiples of 4
+    const float* pa = A + (a_in ? p0 + scol : 0);
+    const float* pb = B + (b_in ? q0 + scol : 0);
+    float4 ra[4], rb[4];
 
+    // Straight-line register staging as in gemm.hip (selects on whole float4 temporaries made
+    // hipcc park the staging registers in scratch memory): loads are unconditional with the
+    // row clamped into the slice; rows past its end and columns past P / Q are zeroed
+    // component-wise when the registers go to LDS one iteration later.
 #define HD_TN_LOAD(r0)                                                                       \
     {                                                                                        \
         _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                      \
-            const int r = (r0) + arow + 8 * p;                                               \
-            const int rc = r < r_end ? r : r_end - 1;                                        \
-            const float4 v = *reinterpret_cast<const float4*>(pa + (size_t)rc * lda);        \
-            ra[p] = (r < r_end && a_in) ? v : zero4;                                         \
+            int r = (r0) + srow + 8 * p;                                                     \
+            r = r < r_end ? r : r_end - 1;                                                   \
+            ra[p] = *reinterpret_cast<const float4*>(pa + (size_t)r * lda);                  \
+            rb[p] = *reinterpret_cast<const float4*>(pb + (size_t)r * ldb);                  \
         }                                                                                    \
-        _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                      \
-            const int r = (r0) + brow + 16 * p;                                              \
-            const int rc = r < r_end ? r : r_end - 1;                                        \
-            const float4 v = *reinterpret_cast<const float4*>(pb + (size_t)rc * ldb);        \
-            rb[p] = (r < r_end && b_in) ? v : zero4;                                         \
+    }
+#define HD_TN_STORE(r0)                                                                      \
+    {                                                                                        \
+        _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                      \
+            const bool rin = (r0) + srow + 8 * p < r_end;                                    \
+            const bool oa = rin && a_in, ob = rin && b_in;                                   \
+            float4 v = ra[p];                                                                \
+            v.x = oa ? v.x : 0.f; v.y = oa ? v.y : 0.f; v.z = oa ? v.z : 0.f; v.w = oa ? v.w : 0.f; \
+            *reinterpret_cast<float4*>(&sA[(srow + 8 * p) * TP + scol]) = v;                 \
+            float4 u = rb[p];                                                                \
+            u.x = ob ? u.x : 0.f; u.y = ob ? u.y : 0.f; u.z = ob ? u.z : 0.f; u.w = ob ? u.w : 0.f; \
+            *reinterpret_cast<float4*>(&sB[(srow + 8 * p) * TQ + scol]) = u;                 \
         }                                                                                    \
     }
 
-    f32x16 acc[2];
+    f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int fi = lane & 31, fh = lane >> 5;
+    // a wavefront whose 64x64 quadrant lies entirely beyond P or Q (ragged last tile row /
+    // column) skips its MFMAs; it still stages and synchronises
+    const bool wave_live = (p0 + wr * 64 < P) && (q0 + wc * 64 < Q);
+    const float* fpa = &sA[fh * TP + wr * 64 + fi];
+    const float* fpb = &sB[fh * TQ + wc * 64 + fi];
     if (r_begin < r_end) {
         HD_TN_LOAD(r_begin)
+        if (!wave_live) {       // staging-only copy of the loop (same barrier count), see gemm.hip
+            for (int r0 = r_begin; r0 < r_end; r0 += TR) {
+                HD_TN_STORE(r0)
+                __syncthreads();
+                HD_TN_LOAD(r0 + TR)
+                __syncthreads();
+            }
+            return;
+        }
         for (int r0 = r_begin; r0 < r_end; r0 += TR) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(&sA[(arow + 8 * p) * TP + acol]) = ra[p];
-#pragma unroll
-            for (int p = 0; p < 2; ++p) *reinterpret_cast<float4*>(&sB[(brow + 16 * p) * TQ + bcol]) = rb[p];
+            HD_TN_STORE(r0)
             __syncthreads();
-            if (r0 + TR < r_end) HD_TN_LOAD(r0 + TR)
+            HD_TN_LOAD(r0 + TR)                                   // past the end: clamped re-read, zeroed
             __builtin_amdgcn_sched_barrier(0);
+            // all fragments of the slab first (64 registers), then 64 MFMAs: the LDS latency of
+            // step s+1.. hides behind the matrix pipe instead of stalling every group of four
+            float fa[TR / 2][2], fb[TR / 2][2];
 #pragma unroll
             for (int s = 0; s < TR / 2; ++s) {
-                const int m = 2 * s + fh;
-                const float b = sB[m * TQ + wc * 32 + fi];
-                const float a0 = sA[m * TP + wr * 64 + fi];
-                const float a1 = sA[m * TP + wr * 64 + 32 + fi];
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+                fa[s][0] = fpa[2 * s * TP];
+                fa[s][1] = fpa[2 * s * TP + 32];
+                fb[s][0] = fpb[2 * s * TQ];
+                fb[s][1] = fpb[2 * s * TQ + 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead of the MFMAs (hipcc re-serialises them)
+#pragma unroll
+            for (int s = 0; s < TR / 2; ++s) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][0], fb[s][0], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][0], fb[s][1], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][1], fb[s][0], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][1], fb[s][1], acc[1][1], 0, 0, 0);
             }
             __syncthreads();
         }
     }
 #undef HD_TN_LOAD
+#undef HD_TN_STORE
 
-    float* out = C + (size_t)blockIdx.y * slice_stride;
-    const int cq = q0 + wc * 32 + fi;
-    if (cq < Q) {
+    float* out = C + (size_t)slice * slice_stride;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int cq = q0 + wc * 64 + j * 32 + fi;
+        if (cq >= Q) continue;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rp = p0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (rp < P) out[(size_t)rp * ldc + cq] = acc[i][r];
+                if (rp < P) out[(size_t)rp * ldc + cq] = acc[i][j][r];
             }
     }
 }
@@ -176,9 +222,11 @@ __global__ __launch_bounds__(256) void scale_by_dev(const float* __restrict__ d,
 }
 
 inline int pick_splits(int64_t R, int64_t tiles) {
-    // enough workgroups for 4 per CU on 256 CUs, each with at least 8 slabs of 32 rows
-    int64_t s = (1024 + tiles - 1) / tiles;
-    const int64_t smax = (R + 255) / 256;
+    // about 4 workgroups per CU on 256 CUs, a multiple of 8 slices (whole slices per XCD),
+    // every slice at least 64 rows
+    int64_t s = (1024 / tiles) / 8 * 8;
+    if (s < 8) s = 8;
+    const int64_t smax = R / 64;
     if (s > smax) s = smax;
     if (s < 1) s = 1;
     if (s > 64) s = 64;
@@ -219,17 +267,17 @@ extern "C" int hd_gemm_tn_f32(const void* A, const void* B, void* C, int64_t R, 
     if (nsl > 1) {
         HD_REQUIRE(workspace, "hd_gemm_tn_f32: workspace of hd_gemm_tn_workspace_floats() floats required");
         HD_REQUIRE(ldc == Q, "hd_gemm_tn_f32: split reduction needs a contiguous output (ldc == Q)");
-        gemm_tn_f32_mfma<<<dim3((unsigned)(tiles_p * tiles_q), (unsigned)nsl), 256, 0, s>>>(
+        gemm_tn_f32_mfma<<<dim3((unsigned)(tiles_p * tiles_q * nsl)), 256, 0, s>>>(
             (const float*)A, (const float*)B, (float*)workspace, (int)R, (int)P, (int)Q, (int)lda, (int)ldb, (int)Q, chunk,
-            tiles_q, (size_t)P * Q);
+            tiles_q, tiles_p * tiles_q, tiles_p * tiles_q * nsl, (size_t)P * Q);
         const size_t count = (size_t)P * Q;
         int blocks = (int)((count + 255) / 256);
         blocks = blocks < 2048 ? blocks : 2048;
         reduce_slices<<<blocks, 256, 0, s>>>((const float*)workspace, nsl, count, count, (float*)C);
     } else {
-        gemm_tn_f32_mfma<<<dim3((unsigned)(tiles_p * tiles_q), 1u), 256, 0, s>>>(
+        gemm_tn_f32_mfma<<<dim3((unsigned)(tiles_p * tiles_q)), 256, 0, s>>>(
             (const float*)A, (const float*)B, (float*)C, (int)R, (int)P, (int)Q, (int)lda, (int)ldb, (int)ldc, chunk,
-            tiles_q, 0);
+            tiles_q, tiles_p * tiles_q, tiles_p * tiles_q, 0);
     }
     return check_launch("hd_gemm_tn_f32");
 }

@@ -106,6 +106,10 @@ class diffusion(nn.Module):
         self.dc = FermiDiracDecoder(r=args.r, t=args.t)
         self._build_tables(num_timesteps)
         self._sign_cache = None
+        # data-parallel runs: `normalization` / `renormal` (:145-153) are global statistics;
+        # when set, the shard-local (sum, sumsq, count) are all-reduced over this process group
+        # (True = default group) so every rank standardises exactly like one GPU would
+        self.sync_moments = None
 
     # ---- schedule (:94-118,173-184): fp64 on the host once, device copies cached ----
     def _build_tables(self, T):
@@ -188,6 +192,9 @@ class diffusion(nn.Module):
         m = torch.empty(3, dtype=torch.float64, device=h.device)
         ops._lib.call("hd_moments", ops._p(h), 1 if h.dtype == torch.float64 else 0, h.numel(), ops._p(ws), ops._p(m),
                       ops._stream())
+        if self.sync_moments is not None:
+            from ..dist import allreduce_moments
+            allreduce_moments(m, None if self.sync_moments is True else self.sync_moments)
         return m
 
     def _apply_moments(self, x, m, inverse):

@@ -59,6 +59,26 @@ def _worker(rank, world, port, q):
     spmm = lambda i, v, s, xx: olayers.spmm_coo(torch.from_numpy(i), torch.from_numpy(v), s, xx)
     out = sh.aggregate(xt[sh.lo:sh.hi], spmm)
     res["agg"] = torch.equal(out, full[sh.lo:sh.hi])
+    # (4) DataParallelTrainer: 3 Adam steps on equal shards == 3 full-batch Adam steps; ranks start
+    #     from different weights (rank 0's are broadcast) and the gradients stay bucket views
+    torch.manual_seed(100 + rank)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.GELU(), torch.nn.Linear(16, 8))
+    tr = hdist.DataParallelTrainer(net, lr=1e-2)
+    torch.manual_seed(100)
+    ref = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.GELU(), torch.nn.Linear(16, 8))
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    xb, yb = torch.randn(40, 8, generator=torch.Generator().manual_seed(3)), torch.randn(
+        40, 8, generator=torch.Generator().manual_seed(4))
+    lo, hi = hdist.shard_range(40, rank, world)
+    for _ in range(3):
+        tr.step(lambda: torch.nn.functional.mse_loss(net(xb[lo:hi]), yb[lo:hi]))
+        opt.zero_grad()
+        torch.nn.functional.mse_loss(ref(xb), yb).backward()
+        opt.step()
+    res["trainer"] = all(torch.allclose(a, b, rtol=1e-5, atol=1e-6) for a, b in zip(net.parameters(), ref.parameters()))
+    flat = tr.bucket.flat
+    res["views"] = all(flat.data_ptr() <= p_.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4
+                       for p_ in net.parameters())
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
