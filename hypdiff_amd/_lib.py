@@ -44,6 +44,14 @@ SIGNATURES = {
     "hd_hb_linear_epilogue*": [P, P, I64, I64, HdCurv, c_int, P],
     "hd_hb_hyp_act*": _act,
     "hd_rownorm*": [P, P, I64, I64, P],
+    "hd_pb_map_bwd*": [c_int, P, P, P, I64, I64, HdCurv, P], "hd_hb_map_bwd*": [c_int, P, P, P, I64, I64, HdCurv, P],
+    "hd_pb_linear_tail_bwd*": [P, P, P, P, P, I64, I64, HdCurv, c_int, P],
+    "hd_hb_linear_tail_bwd*": [P, P, P, I64, I64, HdCurv, c_int, P],
+    "hd_pb_agg_tail*": [P, P, I64, I64, HdCurv, HdCurv, c_int, c_int, P],
+    "hd_hb_agg_tail*": [P, P, I64, I64, HdCurv, HdCurv, c_int, c_int, P],
+    "hd_pb_agg_tail_bwd*": [P, P, P, I64, I64, HdCurv, HdCurv, c_int, c_int, P],
+    "hd_hb_agg_tail_bwd*": [P, P, P, I64, I64, HdCurv, HdCurv, c_int, c_int, P],
+    "hd_rownorm_bwd_add*": [P, P, P, P, I64, I64, P],
     "hd_pb_edge_decode*": [P, P, I64, P, I64, I64, HdCurv, c_int, c_double, c_double, P],
     "hd_hb_edge_decode*": [P, P, I64, P, I64, I64, HdCurv, c_int, c_double, c_double, P],
     "hd_csr_from_coo": [P, P, I64, I64, I64, P, P, P, P],

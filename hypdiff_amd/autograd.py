@@ -231,3 +231,140 @@ def mse_loss(a, b):
 
 def wants_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+# ---- encoder (HGCN / HNN) training: lp_train.py:66-82 --------------------------------------
+MAP_CODES = {"proj": 0, "expmap0": 1, "logmap0": 2, "expmap0_proj": 3}
+
+
+def _f32_only(x, what):
+    if x.dtype != torch.float32:
+        raise NotImplementedError(f"{what}: the backward kernels are fp32 (the reference trains in fp32); "
+                                  f"got {x.dtype} -- run fp64 under torch.no_grad()")
+
+
+class RowMap(torch.autograd.Function):
+    """proj / expmap0 / logmap0 / input lift of either manifold with its VJP kernel."""
+
+    @staticmethod
+    def forward(ctx, x, abi, op, cv):
+        x2, shape = ops._rows(x)
+        out = torch.empty_like(x2)
+        _lib.call(f"hd_{abi}_{op}" + ops._sfx(x2), ops._p(x2), ops._p(out), x2.shape[0], x2.shape[1], cv, ops._stream())
+        ctx.save_for_backward(x2)
+        ctx.meta = (abi, MAP_CODES[op], cv, shape)
+        return out.view(shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x2,) = ctx.saved_tensors
+        abi, which, cv, shape = ctx.meta
+        g2 = g.reshape(x2.shape).contiguous()
+        out = torch.empty_like(x2)
+        _lib.call(f"hd_{abi}_map_bwd" + ops._sfx(x2), which, ops._p(x2), ops._p(g2), ops._p(out), x2.shape[0],
+                  x2.shape[1], cv, ops._stream())
+        return out.view(shape), None, None, None
+
+
+class HbProjTan0(torch.autograd.Function):
+    """hyperboloid.py:64-68: zero the time column; the VJP is the same map on the gradient"""
+
+    @staticmethod
+    def forward(ctx, u, cv):
+        ctx.cv = cv
+        return HbProjTan0._run(u, cv)
+
+    @staticmethod
+    def _run(u, cv):
+        u2 = u.contiguous()
+        out = torch.empty_like(u2)
+        _lib.call("hd_hb_proj_tan0" + ops._sfx(u2), ops._p(u2), ops._p(out), u2.shape[0], u2.shape[1], cv, ops._stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return HbProjTan0._run(g, ctx.cv), None
+
+
+class HypLinearFn(torch.autograd.Function):
+    """proj(mobius_matvec(W, x)) [+ logmap0] (layers/hyp_layers.py:98-101, :134) and its VJP:
+    one row kernel for the tail, the TN MFMA GEMM for dW, the NT GEMM for dx."""
+
+    @staticmethod
+    def forward(ctx, x, w, abi, cv, flags):
+        _f32_only(x, "HypLinear autograd")
+        x2 = x.contiguous()
+        wd = w.detach().to(torch.float32)
+        if abi == "pb":
+            lhs = x2
+            aux = ops.rownorm(x2)
+        else:
+            lhs = torch.empty_like(x2)
+            _lib.call("hd_hb_logmap0_f32", ops._p(x2), ops._p(lhs), x2.shape[0], x2.shape[1], cv, ops._stream())
+            aux = None
+        mx = ops.gemm(lhs, wd)
+        out = torch.empty_like(mx)
+        if abi == "pb":
+            _lib.call("hd_pb_matvec_epilogue_f32", ops._p(mx), ops._p(aux), ops._p(out), mx.shape[0], mx.shape[1], cv,
+                      flags, ops._stream())
+            ctx.save_for_backward(x2, wd, mx, aux)
+        else:
+            _lib.call("hd_hb_linear_epilogue_f32", ops._p(mx), ops._p(out), mx.shape[0], mx.shape[1], cv, flags,
+                      ops._stream())
+            ctx.save_for_backward(x2, wd, mx, lhs)
+        ctx.meta = (abi, cv, flags, x.requires_grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        abi, cv, flags, need_x = ctx.meta
+        x2, wd, mx, aux = ctx.saved_tensors
+        g = g.contiguous()
+        n, dout = mx.shape
+        dmx = torch.empty_like(mx)
+        if abi == "pb":
+            dxn = torch.empty(n, dtype=torch.float32, device=g.device)
+            _lib.call("hd_pb_linear_tail_bwd_f32", ops._p(mx), ops._p(aux), ops._p(g), ops._p(dmx), ops._p(dxn), n, dout,
+                      cv, flags, ops._stream())
+            lhs = x2
+        else:
+            _lib.call("hd_hb_linear_tail_bwd_f32", ops._p(mx), ops._p(g), ops._p(dmx), n, dout, cv, flags, ops._stream())
+            lhs = aux
+        dw = gemm_tn(dmx, lhs)
+        dx = None
+        if need_x:
+            dl = ops.gemm(dmx, transpose(wd))                 # (n, d_in) = dmx @ W
+            dx = torch.empty_like(x2)
+            if abi == "pb":
+                _lib.call("hd_rownorm_bwd_add_f32", ops._p(x2), ops._p(dxn), ops._p(dl), ops._p(dx), n, x2.shape[1],
+                          ops._stream())
+            else:
+                _lib.call("hd_hb_map_bwd_f32", 2, ops._p(x2), ops._p(dl), ops._p(dx), n, x2.shape[1], cv, ops._stream())
+        return dx, dw, None, None, None
+
+
+class HypAggFn(torch.autograd.Function):
+    """[HypAct](proj(expmap0(spmm(adj, xt)))) (layers/hyp_layers.py:150-151, :170-173).  Training
+    forward = hd_spmm_csr (aggregate s kept) + the tail kernel; backward = tail VJP + SpMM with
+    the transposed CSR (rows summed in index order: deterministic, no atomics)."""
+
+    @staticmethod
+    def forward(ctx, xt, csr, abi, cin, cout, act_code, fuse):
+        _f32_only(xt, "HypAgg autograd")
+        s = ops.spmm(csr, xt)
+        out = torch.empty_like(s)
+        _lib.call(f"hd_{abi}_agg_tail_f32", ops._p(s), ops._p(out), s.shape[0], s.shape[1], cin, cout, act_code, fuse,
+                  ops._stream())
+        ctx.save_for_backward(s)
+        ctx.meta = (csr, abi, cin, cout, act_code, fuse)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (s,) = ctx.saved_tensors
+        csr, abi, cin, cout, act_code, fuse = ctx.meta
+        g = g.contiguous()
+        ds = torch.empty_like(s)
+        _lib.call(f"hd_{abi}_agg_tail_bwd_f32", ops._p(s), ops._p(g), ops._p(ds), s.shape[0], s.shape[1], cin, cout,
+                  act_code, fuse, ops._stream())
+        return ops.spmm(csr.transposed(), ds), None, None, None, None, None, None

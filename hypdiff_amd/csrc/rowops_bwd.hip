@@ -1,0 +1,311 @@
+// C-ABI entry points: backward (vector-Jacobian products) of the fused per-row manifold maps.
+//
+// Every forward row kernel computes  out = factor(norms) * row  (plus, on the hyperboloid, a
+// time coordinate that is a function of the spatial norm).  Its VJP is
+//     d_row = factor * d_out + (d factor / d norm) * <row, d_out> / norm * row  (+ time terms)
+// so a backward kernel is one read of the saved row, one read of the incoming gradient and
+// one write -- the same HBM traffic class as the forward map.  The factor and its partial
+// derivatives come from evaluating the forward's scalar chain on dual numbers (hd_dual.cuh).
+// Reference: autograd of manifolds/poincare.py:42-47,73-83,93-102, manifolds/hyperboloid.py:
+// 43-52,90-113,120-123, layers/hyp_layers.py:98-108,133-152,170-173 as lp_train.py:66-82 runs it.
+#include "hd_rowkernels.cuh"
+#include "hd_dual.cuh"
+#include "../../include/hypdiff.h"
+
+using namespace hd;
+
+namespace {
+
+inline Curv mk(const hd_curv& c) { return Curv{c.c, c.sqrt_c, c.K, c.sqrt_K}; }
+
+// ---- Poincare-ball scalar chains (S = Dual<T,NV>) ----------------------------------------
+template <typename T, class S> __device__ __forceinline__ S pb_proj_f(const S& rn, const Curv& cv) {
+    const S n = d_clamp_min(rn, (T)kMinNorm);
+    const T maxnorm = (T)((1.0 - Lim<T>::pb_eps) / cv.sc);
+    if (n.v > maxnorm) return S(maxnorm) / n;
+    return S(T(1));
+}
+template <typename T, class S> __device__ __forceinline__ S pb_expmap0_f(const S& rn, const Curv& cv) {
+    const T sc = (T)cv.sc;
+    const S n = d_clamp_min(rn, (T)kMinNorm);
+    return d_tanh15(n * sc) / (n * sc);
+}
+template <typename T, class S> __device__ __forceinline__ S pb_logmap0_f(const S& rn, const Curv& cv) {
+    const T sc = (T)cv.sc;
+    const S n = d_clamp_min(rn, (T)kMinNorm);
+    return d_artanh(n * sc) * (T(1) / sc) / n;
+}
+
+// g <- f*g + (k/norm)*s  on all columns (k = derivative term already multiplied by <s,g>)
+template <class TL, typename T>
+__device__ __forceinline__ void axpby(TL& g, const TL& s, T f, T k) {
+#pragma unroll
+    for (int i = 0; i < TL::kRegs; ++i) g.v[i] = f * g.v[i] + k * s.v[i];
+}
+
+// ---------------------------------------------------------------------------------------
+// standalone maps: which = 0 proj, 1 expmap0, 2 logmap0, 3 proj(expmap0(.))
+template <typename T> struct PbMapBwd {
+    Curv cv;
+    int which;
+    template <class TL> __device__ __forceinline__ void operator()(TL& x, TL& g, int64_t) const {
+        using S = Dual<T, 1>;
+        const T nr = hd_sqrt(x.sumsq());
+        const S n = S::var(nr, 0);
+        S f;
+        if (which == 0) f = pb_proj_f<T>(n, cv);
+        else if (which == 1) f = pb_expmap0_f<T>(n, cv);
+        else if (which == 2) f = pb_logmap0_f<T>(n, cv);
+        else { f = pb_expmap0_f<T>(n, cv); f = f * pb_proj_f<T>(f * n, cv); }
+        const T t = x.dot(g);
+        axpby(g, x, f.v, nr > T(0) ? f.d[0] * t / nr : T(0));
+    }
+};
+
+// hyperboloid: spatial factor f(ns) and time coordinate tau(ns) of expmap0 (+proj)
+template <typename T, class S>
+__device__ __forceinline__ void hb_expmap0_f(const S& ns, const Curv& cv, S& f, S& tau) {
+    const T sK = (T)cv.sK;
+    const S n = d_clamp_min(ns, (T)kMinNorm);
+    S sh, ch;
+    d_sinhcosh15(n / sK, sh, ch);
+    f = sh * sK / n;
+    const S yn = f * ns;
+    tau = d_sqrt(d_clamp_min(yn * yn + (T)cv.K, (T)Lim<T>::hb_eps));
+}
+// logmap0 factor from the time coordinate y0 and the raw spatial norm yn
+template <typename T, class S> __device__ __forceinline__ S hb_logmap0_f(const S& y0, const S& yn, const Curv& cv) {
+    const T sK = (T)cv.sK;
+    const S n = d_clamp_min(yn, (T)kMinNorm);
+    const S theta = d_clamp_min(y0 / sK, (T)(1.0 + Lim<T>::hb_eps));
+    return d_arcosh(theta) * sK / n;
+}
+
+// which = 0 proj, 1 expmap0 (incl. proj), 2 logmap0, 3 input lift (= expmap0 of the spatial part)
+template <typename T> struct HbMapBwd {
+    Curv cv;
+    int which;
+    template <class TL> __device__ __forceinline__ void operator()(TL& x, TL& g, int64_t) const {
+        const T nr = hd_sqrt(x.sumsq(1));
+        const T t = x.dot(g, 1);             // <x_sp, g_sp>
+        const T g0 = g.first();
+        if (which == 2) {
+            using S = Dual<T, 2>;
+            const S f = hb_logmap0_f<T>(S::var(x.first(), 0), S::var(nr, 1), cv);
+            axpby(g, x, f.v, nr > T(0) ? f.d[1] * t / nr : T(0));
+            g.set_first(f.d[0] * t);
+            return;
+        }
+        using S = Dual<T, 1>;
+        const S n = S::var(nr, 0);
+        S f, tau;
+        if (which == 0) {
+            f = S(T(1));
+            tau = d_sqrt(d_clamp_min(n * n + (T)cv.K, (T)Lim<T>::hb_eps));
+        } else {
+            hb_expmap0_f<T>(n, cv, f, tau);
+        }
+        axpby(g, x, f.v, nr > T(0) ? (f.d[0] * t + tau.d[0] * g0) / nr : T(0));
+        g.set_first(T(0));
+    }
+};
+
+// ---- HypLinear tails --------------------------------------------------------------------
+// forward: xt = Phi(|mx|, |x|) * mx  (matvec_epilogue [+proj] [+logmap0]);  returns d_mx in g and
+// d|x| per row (poincare.py:93-102, hyp_layers.py:100-101, :134)
+template <typename T> struct PbLinearTailBwd {
+    Curv cv;
+    const T* xnorm;
+    T* dxnorm;
+    int flags;
+    template <class TL> __device__ __forceinline__ void operator()(TL& mx, TL& g, int64_t row) const {
+        using S = Dual<T, 2>;
+        const T sc = (T)cv.sc;
+        const bool nz = mx.any_nonzero();
+        const T mr = hd_sqrt(mx.sumsq());
+        const T xr = xnorm[row];
+        const S m = S::var(mr, 0);
+        const S xn = xr >= (T)kMinNorm ? S::var(xr, 1) : S((T)kMinNorm);
+        const S mc = d_clamp_min(m, (T)kMinNorm);
+        S f = d_tanh15(mc / xn * d_artanh(xn * sc)) / (mc * sc);
+        if (flags & 1) f = f * pb_proj_f<T>(f * m, cv);
+        if (flags & 2) f = f * pb_logmap0_f<T>(f * m, cv);
+        const T t = mx.dot(g);
+        if (nz) {
+            axpby(g, mx, f.v, mr > T(0) ? f.d[0] * t / mr : T(0));
+            if (g.j == 0) dxnorm[row] = f.d[1] * t;
+        } else {
+            g.zero();
+            if (g.j == 0) dxnorm[row] = T(0);
+        }
+    }
+};
+
+// forward: expmap0 (+proj) (+logmap0) of mu (hyperboloid.py:120-123 tail); column 0 of mu is unused
+template <typename T> struct HbLinearTailBwd {
+    Curv cv;
+    int flags;
+    template <class TL> __device__ __forceinline__ void operator()(TL& mu, TL& g, int64_t) const {
+        using S = Dual<T, 1>;
+        const T nr = hd_sqrt(mu.sumsq(1));
+        const S n = S::var(nr, 0);
+        S f, tau;
+        hb_expmap0_f<T>(n, cv, f, tau);
+        const T t = mu.dot(g, 1);
+        const T g0 = g.first();
+        T k;
+        if (flags & 2) {
+            f = f * hb_logmap0_f<T>(tau, f * n, cv);
+            k = f.d[0] * t;                       // tangent output: time column is identically 0
+        } else {
+            k = f.d[0] * t + tau.d[0] * g0;
+        }
+        axpby(g, mu, f.v, nr > T(0) ? k / nr : T(0));
+        g.set_first(T(0));
+    }
+};
+
+// ---- HypAgg tails (+ fused HypAct) --------------------------------------------------------
+// forward: out = [HypAct](proj(expmap0(s)));  s = spmm(adj, xt) saved by the forward pass
+template <typename T> struct PbAggTailBwd {
+    Curv cin, cout;
+    int act, fuse;
+    template <class TL> __device__ __forceinline__ void operator()(TL& s, TL& g, int64_t) const {
+        using S = Dual<T, 1>;
+        const T sr = hd_sqrt(s.sumsq());
+        const S n = S::var(sr, 0);
+        S f1 = pb_expmap0_f<T>(n, cin);
+        f1 = f1 * pb_proj_f<T>(f1 * n, cin);
+        if (fuse) {
+            f1 = f1 * pb_logmap0_f<T>(f1 * n, cin);
+            // a = act(u), u = f1 * s; second radial chain on |a|
+            TL a = s;
+            const T f1v = f1.v;
+            const int ac = act;
+            a.map([=](T x) { return apply_act(f1v * x, ac); });
+            const T ar = hd_sqrt(a.sumsq());
+            const S na = S::var(ar, 0);
+            S f2 = pb_expmap0_f<T>(na, cout);
+            f2 = f2 * pb_proj_f<T>(f2 * na, cout);
+            const T t2 = a.dot(g);
+            axpby(g, a, f2.v, ar > T(0) ? f2.d[0] * t2 / ar : T(0));      // g = dL/da
+#pragma unroll
+            for (int i = 0; i < TL::kRegs; ++i) g.v[i] *= act_grad(f1v * s.v[i], ac);   // dL/du
+        }
+        const T t1 = s.dot(g);
+        axpby(g, s, f1.v, sr > T(0) ? f1.d[0] * t1 / sr : T(0));
+    }
+};
+
+template <typename T> struct HbAggTailBwd {
+    Curv cin, cout;
+    int act, fuse;
+    template <class TL> __device__ __forceinline__ void operator()(TL& s, TL& g, int64_t) const {
+        using S = Dual<T, 1>;
+        const T sr = hd_sqrt(s.sumsq(1));
+        const S n = S::var(sr, 0);
+        S f1, tau1;
+        hb_expmap0_f<T>(n, cin, f1, tau1);
+        if (!fuse) {
+            const T t = s.dot(g, 1), g0 = g.first();
+            axpby(g, s, f1.v, sr > T(0) ? (f1.d[0] * t + tau1.d[0] * g0) / sr : T(0));
+            g.set_first(T(0));
+            return;
+        }
+        f1 = f1 * hb_logmap0_f<T>(tau1, f1 * n, cin);
+        TL a = s;
+        const T f1v = f1.v;
+        const int ac = act;
+        a.map([=](T x) { return apply_act(f1v * x, ac); });
+        a.set_first(T(0));                                   // proj_tan0 (hyperboloid.py:64-68)
+        const T ar = hd_sqrt(a.sumsq(1));
+        const S na = S::var(ar, 0);
+        S f2, tau2;
+        hb_expmap0_f<T>(na, cout, f2, tau2);
+        const T t2 = a.dot(g, 1), g0 = g.first();
+        axpby(g, a, f2.v, ar > T(0) ? (f2.d[0] * t2 + tau2.d[0] * g0) / ar : T(0));
+#pragma unroll
+        for (int i = 0; i < TL::kRegs; ++i) g.v[i] *= act_grad(f1v * s.v[i], ac);
+        g.set_first(T(0));
+        const T t1 = s.dot(g, 1);
+        axpby(g, s, f1.v, sr > T(0) ? f1.d[0] * t1 / sr : T(0));
+        g.set_first(T(0));
+    }
+};
+
+// forward tails on a stored aggregate (training forward = hd_spmm_csr + this, so that s is saved)
+template <class M, typename T> struct AggTailFwd {
+    Curv cin, cout;
+    int act, fuse;
+    template <class TL> __device__ __forceinline__ void operator()(TL& r, int64_t) const {
+        M::expmap0(r, cin);
+        M::proj(r, cin);
+        if (fuse) hyp_act<M, T>(r, cin, cout, act);
+    }
+};
+
+// g <- g + coef[row] * x / |x|   (d|x| flowing back into the row; 0 for a zero row)
+template <typename T> struct NormBwdAdd {
+    const T* coef;
+    template <class TL> __device__ __forceinline__ void operator()(TL& x, TL& g, int64_t row) const {
+        const T nr = hd_sqrt(x.sumsq());
+        const T k = nr >= (T)kMinNorm ? coef[row] / nr : T(0);
+#pragma unroll
+        for (int i = 0; i < TL::kRegs; ++i) g.v[i] += k * x.v[i];
+    }
+};
+
+template <typename T, class Op>
+int bwd2(const char* name, const void* saved, const void* grad, void* out, int64_t n, int64_t d, Op op, void* st) {
+    return launch_map2<T, int32_t>(name, (const T*)saved, nullptr, (const T*)grad, (T*)out, n, d, op, (hipStream_t)st);
+}
+
+}  // namespace
+
+#define HD_BWD(T, sfx)                                                                                        \
+    extern "C" int hd_pb_map_bwd_##sfx(int which, const void* x, const void* dy, void* dx, int64_t n,        \
+                                       int64_t d, hd_curv c, void* st) {                                      \
+        HD_REQUIRE(which >= 0 && which <= 3, "hd_pb_map_bwd: bad map code");                                  \
+        return bwd2<T>("hd_pb_map_bwd_" #sfx, x, dy, dx, n, d, PbMapBwd<T>{mk(c), which}, st);               \
+    }                                                                                                         \
+    extern "C" int hd_hb_map_bwd_##sfx(int which, const void* x, const void* dy, void* dx, int64_t n,        \
+                                       int64_t d, hd_curv c, void* st) {                                      \
+        HD_REQUIRE(which >= 0 && which <= 3, "hd_hb_map_bwd: bad map code");                                  \
+        return bwd2<T>("hd_hb_map_bwd_" #sfx, x, dy, dx, n, d, HbMapBwd<T>{mk(c), which}, st);               \
+    }                                                                                                         \
+    extern "C" int hd_pb_linear_tail_bwd_##sfx(const void* mx, const void* xnorm, const void* dxt, void* dmx, \
+                                               void* dxnorm, int64_t n, int64_t d, hd_curv c, int flags,      \
+                                               void* st) {                                                    \
+        HD_REQUIRE((xnorm && dxnorm) || n == 0, "hd_pb_linear_tail_bwd: xnorm / dxnorm missing");             \
+        return bwd2<T>("hd_pb_linear_tail_bwd_" #sfx, mx, dxt, dmx, n, d,                                     \
+                       PbLinearTailBwd<T>{mk(c), (const T*)xnorm, (T*)dxnorm, flags}, st);                    \
+    }                                                                                                         \
+    extern "C" int hd_hb_linear_tail_bwd_##sfx(const void* mu, const void* dxt, void* dmu, int64_t n,        \
+                                               int64_t d, hd_curv c, int flags, void* st) {                   \
+        return bwd2<T>("hd_hb_linear_tail_bwd_" #sfx, mu, dxt, dmu, n, d, HbLinearTailBwd<T>{mk(c), flags}, st); \
+    }                                                                                                         \
+    extern "C" int hd_pb_agg_tail_bwd_##sfx(const void* s, const void* dout, void* ds, int64_t n, int64_t d, \
+                                            hd_curv ci, hd_curv co, int act, int fuse, void* st) {            \
+        return bwd2<T>("hd_pb_agg_tail_bwd_" #sfx, s, dout, ds, n, d, PbAggTailBwd<T>{mk(ci), mk(co), act, fuse}, st); \
+    }                                                                                                         \
+    extern "C" int hd_hb_agg_tail_bwd_##sfx(const void* s, const void* dout, void* ds, int64_t n, int64_t d, \
+                                            hd_curv ci, hd_curv co, int act, int fuse, void* st) {            \
+        return bwd2<T>("hd_hb_agg_tail_bwd_" #sfx, s, dout, ds, n, d, HbAggTailBwd<T>{mk(ci), mk(co), act, fuse}, st); \
+    }                                                                                                         \
+    extern "C" int hd_pb_agg_tail_##sfx(const void* s, void* out, int64_t n, int64_t d, hd_curv ci,          \
+                                        hd_curv co, int act, int fuse, void* st) {                            \
+        return launch_map1<T>("hd_pb_agg_tail_" #sfx, (const T*)s, (T*)out, n, d,                            \
+                              AggTailFwd<PB<T>, T>{mk(ci), mk(co), act, fuse}, (hipStream_t)st);              \
+    }                                                                                                         \
+    extern "C" int hd_hb_agg_tail_##sfx(const void* s, void* out, int64_t n, int64_t d, hd_curv ci,          \
+                                        hd_curv co, int act, int fuse, void* st) {                            \
+        return launch_map1<T>("hd_hb_agg_tail_" #sfx, (const T*)s, (T*)out, n, d,                            \
+                              AggTailFwd<HB<T>, T>{mk(ci), mk(co), act, fuse}, (hipStream_t)st);              \
+    }                                                                                                         \
+    extern "C" int hd_rownorm_bwd_add_##sfx(const void* x, const void* coef, const void* g, void* out,       \
+                                            int64_t n, int64_t d, void* st) {                                 \
+        HD_REQUIRE(coef || n == 0, "hd_rownorm_bwd_add: coef missing");                                       \
+        return bwd2<T>("hd_rownorm_bwd_add_" #sfx, x, g, out, n, d, NormBwdAdd<T>{(const T*)coef}, st);       \
+    }
+HD_BWD(float, f32)
+HD_BWD(double, f64)

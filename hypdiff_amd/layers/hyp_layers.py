@@ -73,9 +73,10 @@ class HypLinear(nn.Module):
 
     def _weight(self):
         # weight dropout stays a torch op ahead of the kernel (:99)
+        w = self.weight if torch.is_grad_enabled() else self.weight.detach()
         if self.training and self.dropout > 0:
-            return F.dropout(self.weight.detach(), self.dropout, training=True)
-        return self.weight.detach() if not torch.is_grad_enabled() else self.weight
+            return F.dropout(w, self.dropout, training=True)
+        return w
 
     def forward(self, x, _tangent=False):
         """proj(mobius_matvec(W, x)) [+ bias branch]; `_tangent` (internal) returns
@@ -84,6 +85,9 @@ class HypLinear(nn.Module):
         w = self._weight()
         if not self.use_bias:
             return man.mobius_matvec(w, x, c, _flags=3 if _tangent else 1)
+        if torch.is_grad_enabled() and (w.requires_grad or x.requires_grad):
+            raise NotImplementedError("HypLinear(use_bias=1) has no backward kernels yet (config.py:36 defaults to "
+                                      "bias=0); train with bias=0 or run under torch.no_grad()")
         res = man.mobius_matvec(w, x, c, _flags=1)
         bias = man.proj_tan0(self.bias.detach().view(1, -1), c)
         hyp_bias = man.proj(man.expmap0(bias, c), c)
@@ -113,6 +117,12 @@ class HypAgg(Module):
         """`_tangent_in`: x is already logmap0(x).  `_act` = (c_out, code) fuses HypAct."""
         csr = ops.csr_of(adj)
         xt = x if _tangent_in else self.manifold.logmap0(x, c=self.c)
+        if torch.is_grad_enabled() and xt.requires_grad:
+            from .. import autograd as hag
+            cin = ops.curv(self.c)
+            if _act is None:
+                return hag.HypAggFn.apply(xt, csr, self.manifold.abi, cin, cin, 0, 0)
+            return hag.HypAggFn.apply(xt, csr, self.manifold.abi, cin, ops.curv(_act[0]), _act[1], 1)
         if _act is None:
             return ops.agg(self.manifold.abi, csr, xt, self.c)
         return ops.agg(self.manifold.abi, csr, xt, self.c, _act[0], _act[1])
@@ -133,10 +143,16 @@ class HypAct(Module):
 
     def forward(self, x):
         code = act_code(self.act)
-        if code is not None:
+        if code is not None and not (torch.is_grad_enabled() and x.requires_grad):
             return ops.hyp_act(self.manifold.abi, x, self.c_in, self.c_out, code)
-        man = self.manifold          # unknown callable: activation between two kernels
-        xt = self.act(man.logmap0(x, c=self.c_in))
+        # unknown callable, or training: the activation runs between the logmap0 kernel and the
+        # fused proj_tan0 -> expmap0 -> proj kernel (each with its VJP kernel under autograd)
+        if self.act is None:
+            self_act = lambda t: t
+        else:
+            self_act = self.act
+        man = self.manifold
+        xt = self_act(man.logmap0(x, c=self.c_in))
         xt = man.proj_tan0(xt, c=self.c_out)
         name = "hd_%s_expmap0_proj" % man.abi
         return ops.map1(name, xt, self.c_out)

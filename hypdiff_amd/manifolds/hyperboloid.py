@@ -39,8 +39,11 @@ class Hyperboloid(Manifold):
         return ops.sqdist("hd_hb_sqdist", x, y, c).unsqueeze(-1)
 
     def mobius_matvec(self, m, x, c, _flags=0):  # :120-123
-        ops._dev(m, x); ops._no_grad(m, x)
+        ops._dev(m, x)
         x2 = self._2d(x).contiguous()
+        if torch.is_grad_enabled() and (m.requires_grad or x.requires_grad):
+            from .. import autograd as hag         # training: forward + VJP kernels (lp_train.py:66-82)
+            return hag.HypLinearFn.apply(x2, m, "hb", ops.curv(c), _flags)
         if m.dtype != x2.dtype:
             m = m.to(x2.dtype)
         u = ops.map1("hd_hb_logmap0", x2, c)

@@ -50,8 +50,11 @@ class PoincareBall(Manifold):
     def mobius_matvec(self, m, x, c, _flags=0):  # :93-102
         """x @ m^T on the matrix cores, then the row-norm / tanh / artanh tail in one
         fused row kernel.  `_flags` (internal): 1 = also proj, 2 = then logmap0."""
-        ops._dev(m, x); ops._no_grad(m, x)
+        ops._dev(m, x)
         x2, shape = ops._rows(x)
+        if torch.is_grad_enabled() and (m.requires_grad or x.requires_grad):
+            from .. import autograd as hag         # training: forward + VJP kernels (lp_train.py:66-82)
+            return hag.HypLinearFn.apply(x2, m, "pb", ops.curv(c), _flags).view(shape[:-1] + (m.shape[0],))
         if m.dtype != x2.dtype:
             m = m.to(x2.dtype)
         xn = ops.rownorm(x2)

@@ -62,8 +62,8 @@ def _dev(*ts):
 def _no_grad(*ts):
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts):
         raise NotImplementedError(
-            "hypdiff_amd round 1 ships forward kernels only; call under torch.no_grad() "
-            "(backward kernels are the next row of the build plan)")
+            "this hypdiff_amd op has no backward kernel (autograd covers the denoisers, HypLinear / "
+            "HypAgg / HypAct without bias, and proj / expmap0 / logmap0): call it under torch.no_grad()")
 
 
 def _stream():
@@ -82,7 +82,15 @@ def _rows(x):
 
 
 def map1(name, x, c):
-    _dev(x); _no_grad(x)
+    _dev(x)
+    if torch.is_grad_enabled() and x.requires_grad:
+        from . import autograd as hag
+        _, abi, op = name.split("_", 2)
+        if op == "proj_tan0":
+            return hag.HbProjTan0.apply(x, curv(c))
+        if op in hag.MAP_CODES:
+            return hag.RowMap.apply(x, abi, op, curv(c))
+    _no_grad(x)
     x2, shape = _rows(x)
     out = torch.empty_like(x2)
     _lib.call(name + _sfx(x2), _p(x2), _p(out), x2.shape[0], x2.shape[1], curv(c), _stream())
@@ -197,6 +205,18 @@ class CSR:
 
     def values(self, dtype):
         return self.val if self.val.dtype == dtype else self.val.to(dtype)
+
+    def transposed(self):
+        """CSR of adj^T (backward of torch.spmm w.r.t. its dense operand), built once."""
+        t = getattr(self, "_t", None)
+        if t is None:
+            n = self.shape[0]
+            deg = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
+            rows = torch.repeat_interleave(torch.arange(n, device=self.col.device), deg)
+            t = csr_from_coo(torch.stack([self.col.to(torch.int64), rows]), self.val, (self.shape[1], self.shape[0]))
+            t._t = self
+            self._t = t
+        return t
 
 
 def csr_from_coo(indices, values, shape):

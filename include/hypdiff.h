@@ -101,6 +101,36 @@ HD_DECL2(hd_hb_linear_epilogue, const void* mu, void* out, int64_t rows, int64_t
 HD_DECL2(hd_hb_hyp_act, const void* x, void* out, int64_t rows, int64_t dim, hd_curv c_in, hd_curv c_out,
          int act, void* stream)
 
+/* ---- backward of the row maps (autograd of the encoder as lp_train.py:66-82 trains it) ------
+ * Each is the vector-Jacobian product of one forward entry point above: `saved` row + incoming
+ * gradient -> outgoing gradient, clamps and torch.where branches differentiated the way torch
+ * autograd differentiates the reference's expression, Artanh / Arcosh by their hand-written
+ * backward (utils/math_utils.py:38-41,65-68).  which: 0 proj, 1 expmap0, 2 logmap0,
+ * 3 proj(expmap0(proj_tan0(.))) (input lift). */
+HD_DECL2(hd_pb_map_bwd, int which, const void* x, const void* dy, void* dx, int64_t rows, int64_t dim, hd_curv c,
+         void* stream)
+HD_DECL2(hd_hb_map_bwd, int which, const void* x, const void* dy, void* dx, int64_t rows, int64_t dim, hd_curv c,
+         void* stream)
+/* VJP of hd_pb_matvec_epilogue: d_mx (rows, dim) and d|x| (rows,) from mx, |x| and d_out */
+HD_DECL2(hd_pb_linear_tail_bwd, const void* mx, const void* xnorm, const void* dout, void* dmx, void* dxnorm,
+         int64_t rows, int64_t dim, hd_curv c, int flags, void* stream)
+/* VJP of hd_hb_linear_epilogue */
+HD_DECL2(hd_hb_linear_tail_bwd, const void* mu, const void* dout, void* dmu, int64_t rows, int64_t dim, hd_curv c,
+         int flags, void* stream)
+/* tail of HypAgg (+HypAct) on a stored aggregate s = spmm(adj, xt): the training forward runs
+ * hd_spmm_csr + this so that s is kept for the backward pass; and its VJP */
+HD_DECL2(hd_pb_agg_tail, const void* s, void* out, int64_t rows, int64_t dim, hd_curv c_in, hd_curv c_out, int act,
+         int fuse_act, void* stream)
+HD_DECL2(hd_hb_agg_tail, const void* s, void* out, int64_t rows, int64_t dim, hd_curv c_in, hd_curv c_out, int act,
+         int fuse_act, void* stream)
+HD_DECL2(hd_pb_agg_tail_bwd, const void* s, const void* dout, void* ds, int64_t rows, int64_t dim, hd_curv c_in,
+         hd_curv c_out, int act, int fuse_act, void* stream)
+HD_DECL2(hd_hb_agg_tail_bwd, const void* s, const void* dout, void* ds, int64_t rows, int64_t dim, hd_curv c_in,
+         hd_curv c_out, int act, int fuse_act, void* stream)
+/* out = g + coef[row] * x / |x|: the gradient of the row norm (hd_rownorm) added to g */
+HD_DECL2(hd_rownorm_bwd_add, const void* x, const void* coef, const void* g, void* out, int64_t rows, int64_t dim,
+         void* stream)
+
 /* LPModel.decode, models/base_models.py:152-159: sqdist(h[idx[:,0]], h[idx[:,1]]) for int64 index
  * pairs (n_pairs, 2) gathered in the kernel; fermi_dirac != 0 appends FermiDiracDecoder
  * (layers/layers.py:85-87) probs = 1/(exp((sqdist - r)/t) + 1).  out (n_pairs,) */

@@ -440,6 +440,27 @@ def capture_train(out_dir):
     store["ddpm/loss"] = N(loss)
     for name, p_ in model.named_parameters():
         store["ddpm/grad/" + name] = N(p_.grad)
+    # HGCN encoder (lp_train.py:66-82 trains it through loss.backward()): gradients of
+    # sum(encode(x) * G) w.r.t. the two HypLinear weights, G a fixed Gaussian; models, graphs and
+    # weights are those of layers.npz (same seeds), so only G-seed-derived outputs are stored
+    import scipy.sparse as sp
+    from utils import data_utils
+    from models.base_models import LPModel
+    for kind, n, dim in (("ego", 17, 16), ("ba", 100, 32)):
+        adj = gi.synthetic_graph(kind, n)
+        adj_train = data_utils.mask_edges(adj, 0.05, 0.1, 1432)[0]
+        adj_t, feats = data_utils.process(adj_train, sp.eye(n).tocsr(), 1, 1)
+        for mname, c in (("PoincareBall", 0.6), ("Hyperboloid", 1.0)):
+            torch.manual_seed(1432)
+            model = LPModel(lp_args(mname, c, n, n, dim, 0)).train()
+            h = model.encode(feats, adj_t)[0]
+            G = T(np.random.RandomState(99).standard_normal(tuple(h.shape)).astype(np.float32))
+            (h * G).sum().backward()
+            k = f"encoder/{kind}{n}/{mname}/"
+            store[k + "h"] = N(h)
+            for i, lyr in enumerate(model.encoder.layers):
+                store[k + f"W{i}"] = N(lyr.linear.weight)
+                store[k + f"gradW{i}"] = N(lyr.linear.weight.grad)
     np.savez_compressed(os.path.join(out_dir, "train.npz"), **store)
     print("train", len(store), "arrays")
 

@@ -154,3 +154,101 @@ def test_hip_mlp_grads_vs_oracle_sizes(shape):
         # fp32 sums over n rows vs fp64: bound scales with the gradient's magnitude
         assert_close(fc.weight.grad.cpu(), w.grad, what=f"fc{i}.weight", rtol=1e-5, atol_scale=5e-6)
         assert_close(fc.bias.grad.cpu(), b.grad, what=f"fc{i}.bias", rtol=1e-5, atol_scale=5e-6)
+
+
+# ------------------------------------------------------------------ encoder (HGCN) gradients
+ENC_CASES = [("ego", 17), ("ba", 100)]
+ENC_MAN = [("PoincareBall", 0.6), ("Hyperboloid", 1.0)]
+# weight gradients are sums over rows of products of O(1) terms: fp32 reassociation shows up
+# relative to the largest entry of the gradient
+ET = dict(rtol=2e-5, atol_scale=5e-6)
+
+
+def _enc_G(shape):
+    return np.random.RandomState(99).standard_normal(tuple(shape)).astype(np.float32)
+
+
+@pytest.mark.parametrize("kind,n", ENC_CASES)
+@pytest.mark.parametrize("mname,c", ENC_MAN)
+def test_oracle_encoder_grads_golden(golden, kind, n, mname, c):
+    from oracle import layers as olayers
+    g, gl = golden("train"), golden("layers")
+    k, k0 = f"encoder/{kind}{n}/{mname}/", f"{kind}{n}/"
+    Ws = [torch.from_numpy(g[k + f"W{i}"]).clone().requires_grad_() for i in range(2)]
+    adj = (torch.from_numpy(gl[k0 + "coo_indices"]), torch.from_numpy(gl[k0 + "coo_values"]), (n, n))
+    h = olayers.hgcn_encode(mname, torch.from_numpy(gl[k0 + "features"]), adj, Ws, [c, c, c])
+    assert_close(h.detach(), g[k + "h"], what=k + "h")
+    (h * torch.from_numpy(_enc_G(h.shape))).sum().backward()
+    for i in range(2):
+        assert_close(Ws[i].grad, g[k + f"gradW{i}"], what=k + f"gradW{i}", **ET)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n", ENC_CASES)
+@pytest.mark.parametrize("mname,c", ENC_MAN)
+def test_hip_encoder_grads_golden(golden, kind, n, mname, c):
+    from hypdiff_amd.models.base_models import LPModel
+    g, gl = golden("train"), golden("layers")
+    k, k0 = f"encoder/{kind}{n}/{mname}/", f"{kind}{n}/"
+    dim = g[k + "W0"].shape[0]
+    args = types.SimpleNamespace(manifold=mname, c=c, cuda=0, device="cuda:0", feat_dim=n, n_nodes=n, model="HGCN",
+                                 r=2.0, t=1.0, nb_false_edges=1, nb_edges=1, dim=dim, num_layers=2, act="relu",
+                                 dropout=0.0, bias=0, use_att=0, local_agg=0)
+    lp = LPModel(args).cuda().train()
+    for i, lyr in enumerate(lp.encoder.layers):
+        lyr.linear.weight.data.copy_(torch.from_numpy(g[k + f"W{i}"]))
+    adj = torch.sparse_coo_tensor(torch.from_numpy(gl[k0 + "coo_indices"]).cuda(),
+                                  torch.from_numpy(gl[k0 + "coo_values"]).cuda(), (n, n), check_invariants=False)
+    h = lp.encode(torch.from_numpy(gl[k0 + "features"]).cuda(), adj)[0]
+    assert h.requires_grad
+    assert_close(h.detach().cpu(), g[k + "h"], rtol=3e-5, atol_scale=3e-6, what=k + "h")
+    (h * torch.from_numpy(_enc_G(h.shape)).cuda()).sum().backward()
+    for i, lyr in enumerate(lp.encoder.layers):
+        assert_close(lyr.linear.weight.grad.cpu(), g[k + f"gradW{i}"], what=k + f"gradW{i}", **ET)
+        assert lyr.linear.bias.grad is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mname,c", ENC_MAN)
+def test_hip_manifold_map_grads_vs_oracle(mname, c):
+    """VJP kernels of proj / expmap0 / logmap0 / HypAct (unfused) / HypAgg (unfused) against the
+    oracle's autograd, on rows that exercise the proj clip and the plain regime, fp32."""
+    import hypdiff_amd.manifolds as hm
+    from hypdiff_amd.layers import hyp_layers as L
+    from oracle import layers as olayers
+    from oracle.manifolds import MANIFOLDS
+    man, M = getattr(hm, mname)(), MANIFOLDS[mname]
+    rs = np.random.RandomState(3)
+    n, d = 257, 24
+    scale = np.where(np.arange(n) % 3 == 0, 3.0, 0.2)[:, None]
+    u = (rs.standard_normal((n, d)) * scale).astype(np.float32)
+    Gm = rs.standard_normal((n, d)).astype(np.float32)
+
+    def both(fn_hip, fn_ref, x_np, what, tol=dict(rtol=2e-5, atol_scale=3e-6)):
+        xh = torch.from_numpy(x_np).cuda().requires_grad_()
+        xr = torch.from_numpy(x_np).clone().requires_grad_()
+        yh, yr = fn_hip(xh), fn_ref(xr)
+        assert_close(yh.detach().cpu(), yr.detach(), what=what + " fwd", **tol)
+        (yh * torch.from_numpy(Gm).cuda()).sum().backward()
+        (yr * torch.from_numpy(Gm)).sum().backward()
+        # rows clipped at the ball boundary: d artanh = 1/(1 - z^2) with 1 - z^2 = 8e-3 amplifies the
+        # fp32 rounding of z 125-fold in the reference itself -> slack from its own fp64 evaluation
+        x64 = torch.from_numpy(x_np).double().requires_grad_()
+        (fn_ref(x64) * torch.from_numpy(Gm).double()).sum().backward()
+        assert_close(xh.grad.cpu(), xr.grad, what=what + " grad", exact=x64.grad.numpy(), **tol)
+
+    both(lambda x: man.proj(man.expmap0(man.proj_tan0(x, c), c), c),
+         lambda x: M["proj"](M["expmap0"](M["proj_tan0"](x, c), c), c), u, "expmap0+proj")
+    p = M["proj"](M["expmap0"](M["proj_tan0"](torch.from_numpy(u), c), c), c).numpy()
+    both(lambda x: man.logmap0(x, c), lambda x: M["logmap0"](x, c), p, "logmap0")
+    both(lambda x: man.proj(x, c), lambda x: M["proj"](x, c), p * np.float32(1.0), "proj")
+    act = L.HypAct(man, c, c, torch.nn.functional.relu)
+    both(lambda x: act(x), lambda x: olayers.hyp_act(mname, x, c, c), p, "HypAct")
+    adj_np = gi.synthetic_graph("ba", n)
+    from oracle import adjacency
+    idx, val, shape = adjacency.process_adj(adj_np)
+    adj = torch.sparse_coo_tensor(torch.from_numpy(idx).cuda(), torch.from_numpy(val).cuda(), shape,
+                                  check_invariants=False)
+    agg = L.HypAgg(man, c, d, 0.0, 0, 0)
+    both(lambda x: agg(x, adj), lambda x: olayers.hyp_agg(mname, x, (torch.from_numpy(idx), torch.from_numpy(val), shape), c),
+         p, "HypAgg")
