@@ -54,6 +54,8 @@ SIGNATURES = {
     "hd_rownorm_bwd_add*": [P, P, P, P, I64, I64, P],
     "hd_pb_edge_decode*": [P, P, I64, P, I64, I64, HdCurv, c_int, c_double, c_double, P],
     "hd_hb_edge_decode*": [P, P, I64, P, I64, I64, HdCurv, c_int, c_double, c_double, P],
+    "hd_pb_edge_decode_bwd*": [P, P, I64, P, P, I64, I64, HdCurv, c_int, c_double, c_double, P],
+    "hd_hb_edge_decode_bwd*": [P, P, I64, P, P, I64, I64, HdCurv, c_int, c_double, c_double, P],
     "hd_csr_from_coo": [P, P, I64, I64, I64, P, P, P, P],
     "hd_spmm_csr*": [P, P, P, P, P, I64, I64, P, I64, P],
     "hd_pb_agg*": _agg, "hd_hb_agg*": _agg,

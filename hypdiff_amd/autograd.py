@@ -368,3 +368,35 @@ class HypAggFn(torch.autograd.Function):
         _lib.call(f"hd_{abi}_agg_tail_bwd_f32", ops._p(s), ops._p(g), ops._p(ds), s.shape[0], s.shape[1], cin, cout,
                   act_code, fuse, ops._stream())
         return ops.spmm(csr.transposed(), ds), None, None, None, None, None, None
+
+
+class EdgeDecodeFn(torch.autograd.Function):
+    """LPModel.decode (models/base_models.py:152-159): gather both endpoints, sqdist and the
+    Fermi-Dirac map in one kernel; backward = one VJP kernel writing the two endpoint
+    gradients of every pair, summed per node by a selection-matrix SpMM (no atomics)."""
+
+    @staticmethod
+    def forward(ctx, h, idx, abi, cv, r, t):
+        _f32_only(h, "LPModel.decode autograd")
+        h = h.contiguous()
+        out = torch.empty(idx.shape[0], dtype=h.dtype, device=h.device)
+        _lib.call(f"hd_{abi}_edge_decode_f32", ops._p(h), ops._p(idx), h.shape[0], ops._p(out), idx.shape[0], h.shape[1],
+                  cv, 1, r, t, ops._stream())
+        ctx.save_for_backward(h, idx)
+        ctx.meta = (abi, cv, r, t)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h, idx = ctx.saved_tensors
+        abi, cv, r, t = ctx.meta
+        E = idx.shape[0]
+        g = g.reshape(-1).contiguous()
+        ge = torch.empty(2 * E, h.shape[1], dtype=h.dtype, device=h.device)
+        _lib.call(f"hd_{abi}_edge_decode_bwd_f32", ops._p(h), ops._p(idx), h.shape[0], ops._p(g), ops._p(ge), E, h.shape[1],
+                  cv, 1, r, t, ops._stream())
+        node = torch.cat([idx[:, 0], idx[:, 1]])
+        order = torch.sort(node, stable=True)
+        csr = ops.csr_from_coo(torch.stack([order.values, order.indices]),
+                               torch.ones(2 * E, dtype=h.dtype, device=h.device), (h.shape[0], 2 * E))
+        return ops.spmm(csr, ge), None, None, None, None, None

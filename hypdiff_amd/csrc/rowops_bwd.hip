@@ -255,6 +255,100 @@ template <typename T> struct NormBwdAdd {
     }
 };
 
+// ---- LPModel.decode backward (models/base_models.py:152-159, layers/layers.py:85-87) --------
+// per pair e: probs = 1/(exp((sq - r)/t) + 1), sq = sqdist(h[i], h[j]);  given d probs, writes
+// d h[i] into ge[e] and d h[j] into ge[n_pairs + e]; the caller sums the rows per node with a
+// selection-matrix SpMM (deterministic).  G lanes per pair, rows in registers.
+template <typename T, int G, int VEC, bool HYPERBOLOID>
+__global__ __launch_bounds__(kBlock) void edge_decode_bwd(const T* __restrict__ h, const int64_t* __restrict__ pairs,
+                                                          int64_t n_rows, const T* __restrict__ gprob,
+                                                          T* __restrict__ ge, int64_t n, int d, Curv cv, int fd, T fr,
+                                                          T ft) {
+    constexpr int RPB = kBlock / G;
+    Tile<T, G, VEC> x, y;
+    x.init(d);
+    y.init(d);
+    for (int64_t e = (int64_t)blockIdx.x * RPB + threadIdx.x / G; e < n; e += (int64_t)gridDim.x * RPB) {
+        int64_t ia = pairs[2 * e], ib = pairs[2 * e + 1];
+        ia = ia < 0 ? 0 : (ia >= n_rows ? n_rows - 1 : ia);
+        ib = ib < 0 ? 0 : (ib >= n_rows ? n_rows - 1 : ib);
+        x.load(h + ia * d);
+        y.load(h + ib * d);
+        T gs = gprob[e];                                   // -> d loss / d sqdist
+        if constexpr (HYPERBOLOID) {
+            const T K = (T)cv.K;
+            const T x0 = x.first(), y0 = y.first();
+            const T prod = x.dot(y) - T(2) * x0 * y0;
+            const T raw = -prod / K, lo = (T)(1.0 + Lim<T>::hb_eps);
+            const T theta = raw < lo ? lo : raw;
+            const T a = arcosh_ref(theta);
+            const T sq_raw = K * (a * a);
+            const T sq = sq_raw > T(50) ? T(50) : sq_raw;
+            if (fd) { const T p = T(1) / ((T)exp((double)((sq - fr) / ft)) + T(1)); gs *= -p * (T(1) - p) / ft; }
+            // clamp(max=50) and clamp(min=1+eps) pass gradient only inside the closed range
+            T gt = (sq_raw <= T(50) && raw >= lo) ? gs * T(2) * K * a / hd_sqrt(theta * theta - T(1)) : T(0);
+            gt = -gt / K;                                 // d theta / d<x,y>_L
+            // d<x,y>_L/dx = y with the time component negated
+#pragma unroll
+            for (int i = 0; i < Tile<T, G, VEC>::kRegs; ++i) {
+                const T xv = x.v[i], yv = y.v[i];
+                x.v[i] = gt * yv;
+                y.v[i] = gt * xv;
+            }
+            if (x.j == 0) { x.v[0] = -x.v[0]; y.v[0] = -y.v[0]; }
+        } else {
+            const T c = (T)cv.c, sc = (T)cv.sc;
+            // m = mobius_add(a, y), a = -x (poincare.py:85-91)
+            const T x2 = x.sumsq(), y2 = y.sumsq(), xy = -x.dot(y);
+            const T A = T(1) + T(2) * c * xy + c * y2, B = T(1) - c * x2;
+            const T Draw = T(1) + T(2) * c * xy + c * c * x2 * y2;
+            const bool dlive = Draw >= (T)kMinNorm;
+            const T D = dlive ? Draw : (T)kMinNorm;
+            Tile<T, G, VEC> m = x;
+#pragma unroll
+            for (int i = 0; i < Tile<T, G, VEC>::kRegs; ++i) m.v[i] = (A * (-x.v[i]) + B * y.v[i]) / D;
+            const T mn = hd_sqrt(m.sumsq());
+            const T z = sc * mn;
+            const T dist = artanh_ref(z) * T(2) / sc;
+            const T sq = dist * dist;
+            if (fd) { const T p = T(1) / ((T)exp((double)((sq - fr) / ft)) + T(1)); gs *= -p * (T(1) - p) / ft; }
+            const T zc = z > (T)(1.0 - 1e-15) ? (T)(1.0 - 1e-15) : z;
+            // d sq / d|m| = 2 dist * 2 / (1 - z^2);  d|m|/dm = m/|m| (0 at m = 0, like torch.norm)
+            const T gm_scale = mn > T(0) ? gs * T(2) * dist * T(2) / (T(1) - zc * zc) / mn : T(0);
+            // gm = gm_scale * m ; s_a = <gm,a>, s_p = <gm,y>, s_m = <gm,m>
+            const T ma = -m.dot(x), mp = m.dot(y), mm = mn * mn;
+            const T s_a = gm_scale * ma, s_p = gm_scale * mp, s_m = dlive ? gm_scale * mm : T(0);
+            const T c2 = T(2) * c;
+#pragma unroll
+            for (int i = 0; i < Tile<T, G, VEC>::kRegs; ++i) {
+                const T av = -x.v[i], pv = y.v[i], gmv = gm_scale * m.v[i];
+                const T ga = (A * gmv + c2 * s_a * pv - c2 * s_p * av - s_m * (c2 * pv + c2 * c * y2 * av)) / D;
+                const T gp = (B * gmv + c2 * s_a * (av + pv) - s_m * (c2 * av + c2 * c * x2 * pv)) / D;
+                x.v[i] = -ga;
+                y.v[i] = gp;
+            }
+        }
+        x.store(ge + e * d);
+        y.store(ge + (n + e) * d);
+    }
+}
+
+template <typename T, bool HYPERBOLOID>
+int launch_edge_decode_bwd(const char* name, const void* h, const int64_t* pairs, int64_t n_rows, const void* gprob,
+                           void* ge, int64_t n, int64_t d, hd_curv c, int fd, double r, double t, void* st) {
+    HD_REQUIRE(n >= 0 && d >= 1 && n_rows >= 1, "%s: bad shape", name);
+    if (n == 0) return HD_OK;
+    HD_REQUIRE(h && pairs && gprob && ge, "%s: null pointer", name);
+    const RowCfg cfg = pick_cfg<T>(d, is_aligned16(h) && is_aligned16(ge));
+    HD_REQUIRE(cfg.ok, "%s: dim=%lld exceeds the register-tile limit", name, (long long)d);
+    return dispatch_cfg<T>(cfg, [&](auto g, auto v) {
+        constexpr int G = decltype(g)::value, V = decltype(v)::value;
+        edge_decode_bwd<T, G, V, HYPERBOLOID><<<grid_for_rows(n, G), kBlock, 0, (hipStream_t)st>>>(
+            (const T*)h, pairs, n_rows, (const T*)gprob, (T*)ge, n, (int)d, mk(c), fd, (T)r, (T)t);
+        return check_launch(name);
+    });
+}
+
 template <typename T, class Op>
 int bwd2(const char* name, const void* saved, const void* grad, void* out, int64_t n, int64_t d, Op op, void* st) {
     return launch_map2<T, int32_t>(name, (const T*)saved, nullptr, (const T*)grad, (T*)out, n, d, op, (hipStream_t)st);
@@ -301,6 +395,18 @@ int bwd2(const char* name, const void* saved, const void* grad, void* out, int64
                                         hd_curv co, int act, int fuse, void* st) {                            \
         return launch_map1<T>("hd_hb_agg_tail_" #sfx, (const T*)s, (T*)out, n, d,                            \
                               AggTailFwd<HB<T>, T>{mk(ci), mk(co), act, fuse}, (hipStream_t)st);              \
+    }                                                                                                         \
+    extern "C" int hd_pb_edge_decode_bwd_##sfx(const void* h, const int64_t* pairs, int64_t n_rows,          \
+                                               const void* gprob, void* ge, int64_t n, int64_t d, hd_curv c,  \
+                                               int fermi_dirac, double r, double t, void* st) {               \
+        return launch_edge_decode_bwd<T, false>("hd_pb_edge_decode_bwd_" #sfx, h, pairs, n_rows, gprob, ge, n, d, c, \
+                                                fermi_dirac, r, t, st);                                       \
+    }                                                                                                         \
+    extern "C" int hd_hb_edge_decode_bwd_##sfx(const void* h, const int64_t* pairs, int64_t n_rows,          \
+                                               const void* gprob, void* ge, int64_t n, int64_t d, hd_curv c,  \
+                                               int fermi_dirac, double r, double t, void* st) {               \
+        return launch_edge_decode_bwd<T, true>("hd_hb_edge_decode_bwd_" #sfx, h, pairs, n_rows, gprob, ge, n, d, c, \
+                                               fermi_dirac, r, t, st);                                        \
     }                                                                                                         \
     extern "C" int hd_rownorm_bwd_add_##sfx(const void* x, const void* coef, const void* g, void* out,       \
                                             int64_t n, int64_t d, void* st) {                                 \

@@ -56,11 +56,27 @@ class LPModel(BaseModel):
         if self.manifold_name == 'Euclidean':
             h = self.manifold.normalize(h)
             return self.dc.forward(self.manifold.sqdist(h[idx[:, 0], :], h[idx[:, 1], :], self.c))
-        ops._dev(h); ops._no_grad(h)
-        h = h.contiguous()
+        ops._dev(h)
         idx = idx.to(device=h.device, dtype=torch.int64).contiguous()
+        if torch.is_grad_enabled() and h.requires_grad:
+            from .. import autograd as hag          # training (lp_train.py:66-82)
+            out = hag.EdgeDecodeFn.apply(h, idx, self.manifold.abi, ops.curv(self.c), float(self.dc.r),
+                                         float(self.dc.t))
+            return out.unsqueeze(-1) if self.manifold.name == 'Hyperboloid' else out
+
+        h = h.contiguous()
         out = torch.empty(idx.shape[0], dtype=h.dtype, device=h.device)
         ops._lib.call("hd_%s_edge_decode" % self.manifold.abi + ops._sfx(h), ops._p(h), ops._p(idx), h.shape[0],
                       ops._p(out), idx.shape[0], h.shape[1], ops.curv(self.c), 1, float(self.dc.r), float(self.dc.t),
                       ops._stream())
         return out.unsqueeze(-1) if self.manifold.name == 'Hyperboloid' else out
+
+    def lp_loss(self, h, edges, edges_false):
+        """The loss of compute_metrics (:169-184): BCE of the positive pairs against 1 plus BCE
+        of the sampled negative pairs against 0 (the ROC / AP metrics stay on the host with
+        sklearn, outside the accelerated path).  The two BCE means are scalar glue over the
+        (E,) probabilities; decode and its backward are the kernels."""
+        pos = self.decode(h, edges)
+        neg = self.decode(h, edges_false)
+        loss = torch.nn.functional.binary_cross_entropy(pos, torch.ones_like(pos))
+        return loss + torch.nn.functional.binary_cross_entropy(neg, torch.zeros_like(neg))

@@ -139,6 +139,14 @@ HD_DECL2(hd_pb_edge_decode, const void* h, const int64_t* pairs, int64_t n_rows,
 HD_DECL2(hd_hb_edge_decode, const void* h, const int64_t* pairs, int64_t n_rows, void* out, int64_t n_pairs,
          int64_t dim, hd_curv c, int fermi_dirac, double r, double t, void* stream)
 
+/* VJP of hd_*_edge_decode: gprob (n_pairs,) = d loss / d out; ge (2 * n_pairs, dim) receives
+ * d h[pairs[e,0]] in row e and d h[pairs[e,1]] in row n_pairs + e (the caller sums the rows of
+ * each node with a selection-matrix hd_spmm_csr: deterministic, no atomics). */
+HD_DECL2(hd_pb_edge_decode_bwd, const void* h, const int64_t* pairs, int64_t n_rows, const void* gprob, void* ge,
+         int64_t n_pairs, int64_t dim, hd_curv c, int fermi_dirac, double r, double t, void* stream)
+HD_DECL2(hd_hb_edge_decode_bwd, const void* h, const int64_t* pairs, int64_t n_rows, const void* gprob, void* ge,
+         int64_t n_pairs, int64_t dim, hd_curv c, int fermi_dirac, double r, double t, void* stream)
+
 /* row L2 norms (unclamped), x.norm(dim=-1) of manifolds/poincare.py:95 -> out (rows,) */
 HD_DECL2(hd_rownorm, const void* x, void* out, int64_t rows, int64_t dim, void* stream)
 

@@ -28,6 +28,7 @@ import types
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
@@ -448,8 +449,10 @@ def capture_train(out_dir):
     from models.base_models import LPModel
     for kind, n, dim in (("ego", 17, 16), ("ba", 100, 32)):
         adj = gi.synthetic_graph(kind, n)
-        adj_train = data_utils.mask_edges(adj, 0.05, 0.1, 1432)[0]
+        adj_train, tr, trf = data_utils.mask_edges(adj, 0.05, 0.1, 1432)[:3]
         adj_t, feats = data_utils.process(adj_train, sp.eye(n).tocsr(), 1, 1)
+        neg = trf[:tr.shape[0]]                      # compute_metrics samples nb_edges false edges (:171-172)
+        store[f"encoder/{kind}{n}/pos_edges"], store[f"encoder/{kind}{n}/neg_edges"] = N(tr), N(neg)
         for mname, c in (("PoincareBall", 0.6), ("Hyperboloid", 1.0)):
             torch.manual_seed(1432)
             model = LPModel(lp_args(mname, c, n, n, dim, 0)).train()
@@ -461,6 +464,15 @@ def capture_train(out_dir):
             for i, lyr in enumerate(model.encoder.layers):
                 store[k + f"W{i}"] = N(lyr.linear.weight)
                 store[k + f"gradW{i}"] = N(lyr.linear.weight.grad)
+            # the link-prediction training loss of lp_train.py:71-76 (base_models.py:169-184)
+            model.zero_grad()
+            h = model.encode(feats, adj_t)[0]
+            pos, ng = model.decode(h, tr), model.decode(h, neg)
+            loss = F.binary_cross_entropy(pos, torch.ones_like(pos)) + F.binary_cross_entropy(ng, torch.zeros_like(ng))
+            loss.backward()
+            store[k + "lp_loss"] = N(loss)
+            for i, lyr in enumerate(model.encoder.layers):
+                store[k + f"lp_gradW{i}"] = N(lyr.linear.weight.grad)
     np.savez_compressed(os.path.join(out_dir, "train.npz"), **store)
     print("train", len(store), "arrays")
 

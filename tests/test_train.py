@@ -252,3 +252,49 @@ def test_hip_manifold_map_grads_vs_oracle(mname, c):
     agg = L.HypAgg(man, c, d, 0.0, 0, 0)
     both(lambda x: agg(x, adj), lambda x: olayers.hyp_agg(mname, x, (torch.from_numpy(idx), torch.from_numpy(val), shape), c),
          p, "HypAgg")
+
+
+@pytest.mark.parametrize("kind,n", ENC_CASES)
+@pytest.mark.parametrize("mname,c", ENC_MAN)
+def test_oracle_lp_loss_grads_golden(golden, kind, n, mname, c):
+    """link-prediction loss (base_models.py:169-184) and its weight gradients, oracle autograd"""
+    from oracle import layers as olayers
+    import torch.nn.functional as F
+    g, gl = golden("train"), golden("layers")
+    k, k0 = f"encoder/{kind}{n}/{mname}/", f"{kind}{n}/"
+    Ws = [torch.from_numpy(g[k + f"W{i}"]).clone().requires_grad_() for i in range(2)]
+    adj = (torch.from_numpy(gl[k0 + "coo_indices"]), torch.from_numpy(gl[k0 + "coo_values"]), (n, n))
+    h = olayers.hgcn_encode(mname, torch.from_numpy(gl[k0 + "features"]), adj, Ws, [c, c, c])
+    pos = olayers.lp_decode(mname, h, torch.from_numpy(g[f"encoder/{kind}{n}/pos_edges"]), c, 2.0, 1.0)
+    neg = olayers.lp_decode(mname, h, torch.from_numpy(g[f"encoder/{kind}{n}/neg_edges"]), c, 2.0, 1.0)
+    loss = F.binary_cross_entropy(pos, torch.ones_like(pos)) + F.binary_cross_entropy(neg, torch.zeros_like(neg))
+    loss.backward()
+    assert_close(loss.detach(), g[k + "lp_loss"], what=k + "lp_loss")
+    for i in range(2):
+        assert_close(Ws[i].grad, g[k + f"lp_gradW{i}"], what=k + f"lp_gradW{i}", **ET)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n", ENC_CASES)
+@pytest.mark.parametrize("mname,c", ENC_MAN)
+def test_hip_lp_train_step_golden(golden, kind, n, mname, c):
+    """encode -> decode -> BCE -> backward of lp_train.py:66-82, all VJPs on HIP kernels"""
+    from hypdiff_amd.models.base_models import LPModel
+    g, gl = golden("train"), golden("layers")
+    k, k0 = f"encoder/{kind}{n}/{mname}/", f"{kind}{n}/"
+    dim = g[k + "W0"].shape[0]
+    args = types.SimpleNamespace(manifold=mname, c=c, cuda=0, device="cuda:0", feat_dim=n, n_nodes=n, model="HGCN",
+                                 r=2.0, t=1.0, nb_false_edges=1, nb_edges=1, dim=dim, num_layers=2, act="relu",
+                                 dropout=0.0, bias=0, use_att=0, local_agg=0)
+    lp = LPModel(args).cuda().train()
+    for i, lyr in enumerate(lp.encoder.layers):
+        lyr.linear.weight.data.copy_(torch.from_numpy(g[k + f"W{i}"]))
+    adj = torch.sparse_coo_tensor(torch.from_numpy(gl[k0 + "coo_indices"]).cuda(),
+                                  torch.from_numpy(gl[k0 + "coo_values"]).cuda(), (n, n), check_invariants=False)
+    h = lp.encode(torch.from_numpy(gl[k0 + "features"]).cuda(), adj)[0]
+    loss = lp.lp_loss(h, torch.from_numpy(g[f"encoder/{kind}{n}/pos_edges"]).cuda(),
+                      torch.from_numpy(g[f"encoder/{kind}{n}/neg_edges"]).cuda())
+    loss.backward()
+    assert_close(loss.detach().cpu(), g[k + "lp_loss"], what=k + "lp_loss")
+    for i, lyr in enumerate(lp.encoder.layers):
+        assert_close(lyr.linear.weight.grad.cpu(), g[k + f"lp_gradW{i}"], what=k + f"lp_gradW{i}", **ET)
