@@ -151,3 +151,51 @@ class RowShardedAdj:
         full = self.gather_rows(xt_local, group)
         out = spmm(self.local_indices, self.local_values, self.local_shape, full)
         return out[: self.hi - self.lo]
+
+
+def sharded_hgcn_encode(encoder, x_local, sharded_adj, group=None):
+    """HGCN.encode (models/encoders.py:115-119) for ONE graph whose rows are split over the ranks
+    (config 5).  The input lift, HypLinear and HypAct are row-local; HypAgg needs the tangent rows
+    of remote columns, so every layer is
+
+        local rows:  lift / HypLinear tail -> tangent block (N/P, d)
+        all ranks :  ONE all-gather of the tangent blocks (RCCL over xGMI)
+        local rows:  CSR SpMM over global columns with expmap0 / proj / HypAct fused
+
+    `x_local` holds this rank's rows of the features (Hyperboloid: zero time column already
+    prepended).  Per row the summation order is that of the 1-GPU kernel, so the result is
+    bit-identical to encoder.encode on the whole graph.  Inference path (torch.no_grad())."""
+    from .models.encoders import _lift
+    n_loc = sharded_adj.hi - sharded_adj.lo
+    assert x_local.shape[0] == n_loc, (x_local.shape, n_loc)
+    shard_csr(sharded_adj, x_local.device)
+    csr = sharded_adj._csr
+    h = _lift(encoder.manifold, x_local, encoder.curvatures[0])
+    for layer in encoder.layers:
+        xt = layer.linear.forward(h, _tangent=True)
+        h = shard_aggregate(layer, csr, sharded_adj.gather_rows(xt, group), n_loc)
+    return h
+
+
+def shard_csr(sharded_adj, device):
+    """device CSR of a rank's row block (columns global), built once"""
+    from . import ops
+    if not hasattr(sharded_adj, "_csr"):
+        sharded_adj._csr = ops.csr_from_coo(torch.from_numpy(sharded_adj.local_indices).to(device),
+                                            torch.from_numpy(np.ascontiguousarray(sharded_adj.local_values)).to(device),
+                                            sharded_adj.local_shape)
+    return sharded_adj._csr
+
+
+def shard_aggregate(layer, csr, xt_full, n_loc):
+    """HypAgg + HypAct of one HyperbolicGraphConvolution on a row block: `xt_full` = the
+    all-gathered tangent rows of every rank, result = this rank's n_loc output rows"""
+    from . import ops
+    from .layers.hyp_layers import act_code
+    code = act_code(layer.hyp_act.act)
+    man = layer.agg.manifold
+    if code is not None:
+        out = ops.agg(man.abi, csr, xt_full, layer.agg.c, layer.hyp_act.c_out, code)
+    else:
+        out = layer.hyp_act.forward(ops.agg(man.abi, csr, xt_full, layer.agg.c))
+    return out[:n_loc]

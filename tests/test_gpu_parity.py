@@ -372,3 +372,38 @@ def test_full_size_properties():
             assert_close(H(man.proj(p, 1.0)), H(p), rtol=1e-6, atol_scale=1e-7, what="proj idempotent")
             sd = man.sqdist(p, p, 1.0)
             assert float(sd.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("mname,c", [("PoincareBall", 0.6), ("Hyperboloid", 1.0)])
+def test_row_sharded_encode_equals_full(mname, c):
+    """config 5 path: rows of one graph split over ranks, tangent all-gather per layer.  world = 1
+    through dist.sharded_hgcn_encode; world = 2 and 3 simulated in-process (the all-gather is a
+    concatenation of the padded blocks -- the collective itself is covered by the gloo test).
+    Same per-row summation order as the 1-GPU kernel -> bit-identical."""
+    import types
+    from hypdiff_amd import dist as hdist
+    from hypdiff_amd.models.encoders import HGCN, _lift
+    n, feat, dim = 203, 12, 32
+    idx, val, shape = adjacency.process_adj(gi.synthetic_graph("ba", n))
+    rs = np.random.RandomState(5)
+    x = rs.standard_normal((n, feat)).astype(np.float32) * 0.3
+    if mname == "Hyperboloid":
+        x = np.concatenate([np.zeros((n, 1), np.float32), x], 1)
+    args = types.SimpleNamespace(manifold=mname, c=c, cuda=0, device="cuda:0", feat_dim=x.shape[1], dim=dim,
+                                 num_layers=2, act="relu", dropout=0.0, bias=0, use_att=0, local_agg=0)
+    torch.manual_seed(3)
+    enc = HGCN(torch.tensor([c]).cuda(), args).cuda().eval()
+    adj = torch.sparse_coo_tensor(G(idx), G(val), shape, check_invariants=False)
+    with torch.no_grad():
+        full = enc.encode(G(x), adj)
+        one = hdist.sharded_hgcn_encode(enc, G(x), hdist.RowShardedAdj(idx, val, shape, 0, 1))
+        assert torch.equal(one, full)
+        for world in (2, 3):
+            shards = [hdist.RowShardedAdj(idx, val, shape, r, world) for r in range(world)]
+            hs = [_lift(enc.manifold, G(x[s.lo:s.hi]), enc.curvatures[0]) for s in shards]
+            for layer in enc.layers:
+                xts = [layer.linear.forward(h, _tangent=True) for h in hs]
+                gathered = torch.cat([torch.cat([xt, xt.new_zeros(s.rows_per_rank - xt.shape[0], xt.shape[1])])
+                                      for s, xt in zip(shards, xts)])
+                hs = [hdist.shard_aggregate(layer, hdist.shard_csr(s, "cuda"), gathered, s.hi - s.lo) for s in shards]
+            assert torch.equal(torch.cat(hs), full), world
