@@ -65,6 +65,8 @@ SIGNATURES = {
     "hd_gemm_tn_f32": [P, P, P, I64, I64, I64, I64, I64, I64, P, P],
     "hd_transpose_f32": [P, P, I64, I64, I64, I64, P],
     "hd_colsum_f32": [P, P, I64, I64, I64, P, P],
+    "hd_bias_gelu_f32": [P, P, P, P, I64, I64, c_int, P],
+    "hd_gelu_bwd_f32": [P, P, P, I64, P],
     "hd_mse_forward_f32": [P, P, P, I64, P, P, P],
     "hd_mse_backward_f32": [P, P, P, I64, P],
     "hd_q_sample": [P, c_int, P, c_int, P, P, P, I64, P, P, I64, P, I64, I64, c_int, c_double, c_double,

@@ -400,3 +400,40 @@ class EdgeDecodeFn(torch.autograd.Function):
         csr = ops.csr_from_coo(torch.stack([order.values, order.indices]),
                                torch.ones(2 * E, dtype=h.dtype, device=h.device), (h.shape[0], 2 * E))
         return ops.spmm(csr, ge), None, None, None, None, None
+
+
+# ---- gcndec denoiser (models/direction_diffusion.py:17-44) -----------------------------------
+class GCNConvGelu(torch.autograd.Function):
+    """act(A_norm @ (x W^T) + bias) with A_norm = D^-1/2 (A + I) D^-1/2 as a device CSR (rows =
+    target nodes).  PARITY UNPINNED: torch_geometric.nn.GCNConv is not in the reference tree; this
+    follows its published definition (Kipf & Welling; linear first, bias after the propagation)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, csr, act):
+        x = x.contiguous()
+        wd, bd = w.detach(), b.detach()
+        xw = ops.gemm(x, wd)
+        agg = ops.spmm(csr, xw)
+        out = torch.empty_like(agg)
+        z = torch.empty_like(agg) if (any(ctx.needs_input_grad) and act) else None
+        _lib.call("hd_bias_gelu_f32", ops._p(agg), ops._p(bd), ops._p(out), ops._p(z), agg.shape[0], agg.shape[1],
+                  1 if act else 0, ops._stream())
+        ctx.save_for_backward(x, wd, z)
+        ctx.meta = (csr, act, x.requires_grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wd, z = ctx.saved_tensors
+        csr, act, need_x = ctx.meta
+        g = g.contiguous()
+        if act:
+            dz = torch.empty_like(g)
+            _lib.call("hd_gelu_bwd_f32", ops._p(g), ops._p(z), ops._p(dz), g.numel(), ops._stream())
+        else:
+            dz = g
+        db = colsum(dz)
+        dxw = ops.spmm(csr.transposed(), dz)
+        dw = gemm_tn(dxw, x)
+        dx = ops.gemm(dxw, transpose(wd)) if need_x else None
+        return dx, dw, db, None, None

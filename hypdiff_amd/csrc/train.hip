@@ -13,6 +13,7 @@
 //  * colsum_f32: bias gradients, two-stage column sums.
 //  * mse kernels: F.mse_loss forward (difference + sum of squares) and its gradient.
 #include "hd_common.cuh"
+#include "hd_gelu.cuh"
 #include "../../include/hypdiff.h"
 
 using namespace hd;
@@ -221,6 +222,25 @@ __global__ __launch_bounds__(256) void scale_by_dev(const float* __restrict__ d,
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) out[i] = d[i] * f;
 }
 
+// GCNConv tail (torch_geometric GCNConv: out = A_norm (x W^T) + bias, then F.gelu --
+// models/direction_diffusion.py:28-37): out = gelu(x + bias[col]); z (optional) = x + bias
+__global__ __launch_bounds__(256) void bias_gelu(const float* __restrict__ x, const float* __restrict__ bias,
+                                                 float* __restrict__ out, float* __restrict__ z, size_t rows, int dim,
+                                                 int act) {
+    const size_t count = rows * (size_t)dim;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        const float v = x[i] + (bias ? bias[i % dim] : 0.f);
+        if (z) z[i] = v;
+        out[i] = act ? gelu_erf(v) : v;
+    }
+}
+// dz = g * gelu'(z)
+__global__ __launch_bounds__(256) void gelu_bwd(const float* __restrict__ g, const float* __restrict__ z,
+                                                float* __restrict__ dz, size_t count) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256)
+        dz[i] = g[i] * gelu_erf_grad(z[i]);
+}
+
 inline int pick_splits(int64_t R, int64_t tiles) {
     // about 4 workgroups per CU on 256 CUs, a multiple of 8 slices (whole slices per XCD),
     // every slice at least 64 rows
@@ -347,4 +367,26 @@ extern "C" int hd_mse_backward_f32(const void* diff, const void* grad_loss, void
                                                                 (float)(2.0 / (double)count), (float*)grad_out,
                                                                 (size_t)count);
     return check_launch("hd_mse_backward_f32");
+}
+
+extern "C" int hd_bias_gelu_f32(const void* x, const void* bias, void* out, void* z, int64_t rows, int64_t dim, int act,
+                                void* st) {
+    HD_REQUIRE(rows >= 0 && dim >= 1 && dim < (1LL << 31), "hd_bias_gelu_f32: bad shape");
+    if (rows == 0) return HD_OK;
+    HD_REQUIRE(x && out, "hd_bias_gelu_f32: null pointer");
+    int64_t blocks = (rows * dim + 255) / 256;
+    blocks = blocks < 4096 ? blocks : 4096;
+    bias_gelu<<<(unsigned)blocks, 256, 0, (hipStream_t)st>>>((const float*)x, (const float*)bias, (float*)out, (float*)z,
+                                                             (size_t)rows, (int)dim, act);
+    return check_launch("hd_bias_gelu_f32");
+}
+
+extern "C" int hd_gelu_bwd_f32(const void* g, const void* z, void* dz, int64_t count, void* st) {
+    HD_REQUIRE(count >= 0, "hd_gelu_bwd_f32: bad size");
+    if (count == 0) return HD_OK;
+    HD_REQUIRE(g && z && dz, "hd_gelu_bwd_f32: null pointer");
+    int64_t blocks = (count + 255) / 256;
+    blocks = blocks < 4096 ? blocks : 4096;
+    gelu_bwd<<<(unsigned)blocks, 256, 0, (hipStream_t)st>>>((const float*)g, (const float*)z, (float*)dz, (size_t)count);
+    return check_launch("hd_gelu_bwd_f32");
 }

@@ -8,8 +8,9 @@ The per-row Python loops of the reference (:158-161, :305-306, :328-330, :350-35
 are single kernels here.  T, the prior horizon and c default to the reference's
 hard-coded 200 / 500 / 1.0 and can be overridden (config 2 uses T = 1000).
 
-The PyG-based `gcndec` denoiser (graphset=False) is not built: torch_geometric's
-GCNConv arithmetic is outside the reference tree (parity unpinned).
+The PyG-based `gcndec` denoiser (graphset=False) is built from GCNConv's published
+definition: torch_geometric is outside the reference tree, so that path is PARITY UNPINNED
+(checked against a CPU restatement of that definition only).
 """
 from collections import namedtuple
 
@@ -35,6 +36,94 @@ class FermiDiracDecoder(nn.Module):
 
     def forward(self, dist):
         return 1. / (torch.exp((dist - self.r) / self.t) + 1.0)
+
+
+def gcn_norm_csr(edge_index, num_nodes):
+    """torch_geometric gcn_norm (add_remaining_self_loops, unit edge weights, symmetric
+    normalisation, flow source -> target) as a device CSR whose row i lists the sources of node i:
+    out[i] = sum_j deg_i^-1/2 deg_j^-1/2 x[j].  Index preparation with torch ops, once per
+    adjacency (cached on the tensor); the SpMM itself is hd_spmm_csr."""
+    cached = getattr(edge_index, "_hd_gcn_csr", None)
+    if cached is not None and cached.shape[0] == num_nodes:
+        return cached
+    src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
+    keep = src != dst
+    loops = torch.arange(num_nodes, device=edge_index.device)
+    src, dst = torch.cat([src[keep], loops]), torch.cat([dst[keep], loops])
+    deg = torch.zeros(num_nodes, dtype=torch.float32, device=edge_index.device).index_add_(
+        0, dst, torch.ones_like(dst, dtype=torch.float32))
+    dis = deg.pow(-0.5)
+    dis[torch.isinf(dis)] = 0
+    w = dis[src] * dis[dst]
+    order = torch.sort(dst, stable=True).indices
+    csr = ops.csr_from_coo(torch.stack([dst[order], src[order]]), w[order].contiguous(), (num_nodes, num_nodes))
+    try:
+        edge_index._hd_gcn_csr = csr
+    except Exception:
+        pass
+    return csr
+
+
+class GCNConv(nn.Module):
+    """Stand-in for torch_geometric.nn.GCNConv (state_dict keys `lin.weight`, `bias`), glorot /
+    zeros initialisation.  PARITY UNPINNED (third-party arithmetic outside the reference tree)."""
+
+    def __init__(self, in_channels, out_channels):
+        super(GCNConv, self).__init__()
+        self.lin = nn.Linear(in_channels, out_channels, bias=False)
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        nn.init.xavier_uniform_(self.lin.weight)
+
+    def forward(self, x, edge_index, _act=False):
+        if edge_index.is_sparse:        # p_sample hands the sparse adjacency itself (:255); pattern only
+            edge_index = edge_index._indices()
+        csr = gcn_norm_csr(edge_index, x.shape[0])
+        return hag.GCNConvGelu.apply(x, self.lin.weight, self.bias, csr, _act)
+
+
+class gcndec(nn.Module):
+    """models/direction_diffusion.py:17-44: 4 x GCNConv + 3 x Linear, exact-erf GELU between.
+    Each GCNConv = MFMA GEMM -> CSR SpMM -> bias+GELU kernel; fc1..fc3 = one LinearStack."""
+
+    def __init__(self, input_dim):
+        super(gcndec, self).__init__()
+        self.conv1 = GCNConv(input_dim + 1, 64)
+        self.conv2 = GCNConv(64, 128)
+        self.conv3 = GCNConv(128, 256)
+        self.conv4 = GCNConv(256, 128)
+        self.fc1 = nn.Linear(128, 256)
+        self.fc2 = nn.Linear(256, 128)
+        self.fc3 = nn.Linear(128, input_dim)
+
+    def forward(self, x, adj, t):
+        ops._dev(x)
+        x = x.contiguous()
+        n, d = x.shape
+        ld = (d + 1 + 3) // 4 * 4
+        h = torch.empty(n, ld, dtype=torch.float32, device=x.device)
+        if torch.is_tensor(t):
+            if t.dtype == torch.int64:
+                kind, tp, ts = 0, t.contiguous(), 0.0
+            else:
+                tp = t.to(torch.float32).contiguous()
+                kind, ts = 1, 0.0
+        else:
+            kind, tp, ts = 2, None, float(t)
+        ops._lib.call("hd_mlp_pack_input", ops._p(x), 1 if x.dtype == torch.float64 else 0, ops._p(tp), kind, ts,
+                      ops._p(h), n, d, ld, ops._stream())
+        w1 = self.conv1.lin.weight
+        if ld != d + 1:         # zero-padded copy of the first weight (differentiable slice-assign)
+            w1 = torch.zeros(w1.shape[0], ld, dtype=w1.dtype, device=w1.device).index_copy(
+                1, torch.arange(d + 1, device=w1.device), w1)
+        csr = gcn_norm_csr(adj._indices() if adj.is_sparse else adj, n)
+        h = hag.GCNConvGelu.apply(h, w1, self.conv1.bias, csr, True)
+        for conv in (self.conv2, self.conv3, self.conv4):
+            h = hag.GCNConvGelu.apply(h, conv.lin.weight, conv.bias, csr, True)
+        if hag.wants_grad(h, *self.parameters()):
+            return hag.linear_stack(h, [self.fc1, self.fc2, self.fc3], (hag.GELU, hag.GELU, hag.LIN))
+        h = ops.gemm(h, self.fc1.weight.detach(), self.fc1.bias.detach(), epi=1)
+        h = ops.gemm(h, self.fc2.weight.detach(), self.fc2.bias.detach(), epi=1)
+        return ops.gemm(h, self.fc3.weight.detach(), self.fc3.bias.detach(), epi=0)
 
 
 class mlp(nn.Module):
@@ -98,6 +187,7 @@ class diffusion(nn.Module):
         device = torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
         self.device = device
         self.prior = 1
+        self.gcn = gcndec(dim).to(device)
         self.mlp = mlp(dim).to(device)
         self.num_timesteps = num_timesteps
         self.prior_horizon = prior_horizon
@@ -239,25 +329,32 @@ class diffusion(nn.Module):
 
     def model_predictions(self, x, adj, t, x_self_cond=None, graphset=False):
         """:248-260"""
-        if not graphset:
-            raise NotImplementedError("gcndec (torch_geometric GCNConv) denoiser: parity unpinned, not built; "
-                                      "use graphset=True (mlp denoiser)")
-        x_start = self.mlp(x, t)
+        x_start = self._denoise(x, adj, t, graphset)
         return ModelPrediction(self.predict_noise_from_start(x, t, x_start), x_start)
+
+    def edge(self, adj):
+        """:216-227"""
+        return torch.stack([adj._indices()[0], adj._indices()[1]], dim=0).to(torch.long)
+
+    def _denoise(self, x, adj, t, graphset):
+        """mlp (graphset=True) or gcndec on the adjacency pattern (:252-255)"""
+        if graphset:
+            return self.mlp(x, t)
+        if adj is None or not torch.is_tensor(adj):
+            raise ValueError("graphset=False runs the gcndec denoiser and needs the adjacency (sparse COO tensor "
+                             "or (2, nnz) edge_index)")
+        return self.gcn(x, adj, t)
 
     def p_sample(self, x, h, adj, direction, labels, u0, t: int, x_self_cond=None, graphset=False):
         """:272-291 -> (pred_img_t fp64, x_start fp32 clamped).  Denoiser = 5 GEMM launches,
         everything after it (predict_noise_from_start, clamp_, sign flip, q_sample at t-1)
         = one fused elementwise kernel."""
-        if not graphset:
-            raise NotImplementedError("gcndec (torch_geometric GCNConv) denoiser: parity unpinned, not built; "
-                                      "use graphset=True (mlp denoiser)")
         ops._dev(x); ops._no_grad(x)
         x = x.contiguous()
         n, d = x.shape
         t = int(t)
         t2 = t - 1 if t > 0 else 0
-        x_start = self.mlp(x, t)                    # integer t is the denoiser feature (:276-278)
+        x_start = self._denoise(x, adj, t, graphset)      # integer t is the denoiser feature (:276-278)
         signs = self._signs(direction)
         lab = ops.labels_dev(labels, x.device)
         out = torch.empty(n, d, dtype=torch.float64, device=x.device)
@@ -278,8 +375,6 @@ class diffusion(nn.Module):
 
     def p_sample_loop(self, x, adj, lables, u0, return_all_timesteps=False, graphset=False, img=None):
         """:293-332.  `img` optionally injects the initial Gaussian (tests)."""
-        if not graphset:
-            raise NotImplementedError("gcndec denoiser not built; use graphset=True")
         shape = x.shape
         img = torch.randn(shape, device=x.device) if img is None else img.clone()
         direction = self.directions(u0)
@@ -289,7 +384,7 @@ class diffusion(nn.Module):
         img = img + self._apply_moments(h, m, 0)
         imgs = [img]
         for t in reversed(range(0, self.num_timesteps)):
-            img, x_start = self.p_sample(img, None, 1, direction, lables, u0, t, None, True)
+            img, x_start = self.p_sample(img, None, adj, direction, lables, u0, t, None, graphset)
             if return_all_timesteps:
                 imgs.append(img)
         ret = img if not return_all_timesteps else torch.stack(imgs, dim=1)
@@ -302,8 +397,6 @@ class diffusion(nn.Module):
         """:335-363 training loss; differentiable w.r.t. the denoiser parameters
         (loss.backward() runs hd_gemm_tn_f32 / hd_gemm_f32_ex kernels, hypdiff_amd/autograd.py).
         `t` / `noise` optionally inject the draws."""
-        if not graphset:
-            raise NotImplementedError("gcndec denoiser not built; use graphset=True")
         x = x.to(torch.float64)
         b, n = x.shape
         t = torch.randint(0, self.num_timesteps, (b,), device=x.device).long() if t is None else t
@@ -316,5 +409,8 @@ class diffusion(nn.Module):
         x_start = self.normalization(x_start)
         xt = self.q_sample(x_start=x_start, t=t, direction=direction, noise=noise, labels=labels, u0=u0,
                            restrict=True)
-        out = self.mlp(xt, t / self.num_timesteps)
+        if graphset:
+            out = self.mlp(xt, t / self.num_timesteps)
+        else:
+            out = self.gcn(xt, self.edge(adj) if adj.is_sparse else adj, t / self.num_timesteps)
         return hag.mse_loss(out, x_start.to(torch.float32))

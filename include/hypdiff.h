@@ -210,6 +210,12 @@ int64_t hd_mse_workspace_doubles(void);
 int hd_mse_forward_f32(const void* a, const void* b, void* diff, int64_t count, void* workspace, void* loss,
                        void* stream);
 int hd_mse_backward_f32(const void* diff, const void* grad_loss, void* grad_out, int64_t count, void* stream);
+/* GCNConv tail of the gcndec denoiser (models/direction_diffusion.py:28-37; torch_geometric
+ * GCNConv adds its bias after the propagation, F.gelu follows): out = act ? gelu(x + bias) :
+ * x + bias; z (optional) receives x + bias for the backward pass.  hd_gelu_bwd: dz = g * gelu'(z). */
+int hd_bias_gelu_f32(const void* x, const void* bias, void* out, void* z, int64_t rows, int64_t dim, int act,
+                     void* stream);
+int hd_gelu_bwd_f32(const void* g, const void* z, void* dz, int64_t count, void* stream);
 /* double-precision x @ W^T (+bias) for fp64 HypLinear */
 int hd_gemm_f64(const void* A, const void* W, const void* bias, void* C, int64_t M, int64_t N, int64_t K,
                 int64_t lda, int64_t ldw, int64_t ldc, void* stream);

@@ -298,3 +298,67 @@ def test_hip_lp_train_step_golden(golden, kind, n, mname, c):
     assert_close(loss.detach().cpu(), g[k + "lp_loss"], what=k + "lp_loss")
     for i, lyr in enumerate(lp.encoder.layers):
         assert_close(lyr.linear.weight.grad.cpu(), g[k + f"lp_gradW{i}"], what=k + f"lp_gradW{i}", **ET)
+
+
+# ------------------------------------------------------------------ gcndec (PARITY UNPINNED)
+@pytest.mark.gpu
+def test_hip_gcndec_vs_oracle():
+    """gcndec forward, training loss gradients and one p_sample step against the oracle's
+    restatement of GCNConv's published definition (torch_geometric is absent: parity unpinned,
+    no reference vectors exist for this path)."""
+    from oracle import gcn as ogcn, adjacency
+    from hypdiff_amd.models.direction_diffusion import diffusion
+    n, dim = 203, 16
+    idx, val, shape = adjacency.process_adj(gi.synthetic_graph("ba", n))
+    adj = torch.sparse_coo_tensor(torch.from_numpy(idx).cuda(), torch.from_numpy(val).cuda(), shape,
+                                  check_invariants=False)
+    torch.manual_seed(11)
+    d = diffusion(types.SimpleNamespace(r=2.0, t=1.0), dim).train()
+    with torch.no_grad():
+        for p in d.gcn.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.1)
+    case = gi.diffusion_case(n, dim, 3)
+    rs = np.random.RandomState(4)
+    t = torch.from_numpy(rs.randint(0, 200, size=n).astype(np.int64))
+    # forward of the denoiser alone
+    x = torch.from_numpy(rs.standard_normal((n, dim)))
+    convs = [(getattr(d.gcn, f"conv{i}").lin.weight.detach().cpu().double().requires_grad_(),
+              getattr(d.gcn, f"conv{i}").bias.detach().cpu().double().requires_grad_()) for i in range(1, 5)]
+    fcs = [(getattr(d.gcn, f"fc{i}").weight.detach().cpu().double().requires_grad_(),
+            getattr(d.gcn, f"fc{i}").bias.detach().cpu().double().requires_grad_()) for i in range(1, 4)]
+    ei = torch.from_numpy(idx)
+    with torch.no_grad():
+        got = d.gcn(x.cuda(), adj, (t / 200).cuda())
+        want = ogcn.gcndec(x, ei, (t / 200).double(), convs, fcs)
+    assert_close(got.cpu(), want, what="gcndec fwd", atol_scale=3e-6)
+    # training loss + gradients (diff.py:113-118 with graphset=False)
+    loss = d(torch.from_numpy(case["x"].copy()).cuda(), adj, case["labels"], torch.from_numpy(case["u0"]).cuda(),
+             restrict=True, graphset=False, t=t.cuda(), noise=torch.from_numpy(case["noise"].copy()).cuda())
+    loss.backward()
+    tables = odiff.schedule(200)
+    xs = odiff.pb_logmap(torch.from_numpy(case["u0"])[torch.from_numpy(case["labels"])].double(),
+                         torch.from_numpy(case["x"]).double(), 1.0)
+    xs = odiff.normalization(xs)
+    xt = odiff.q_sample(xs, t, torch.from_numpy(case["noise"].copy()), odiff.sign_table(torch.from_numpy(case["u0"])),
+                        case["labels"], tables, restrict=True)
+    out = ogcn.gcndec(xt, ei, (t / 200).double(), convs, fcs)
+    ref = torch.nn.functional.mse_loss(out, xs.float().double())
+    ref.backward()
+    assert_close(loss.detach().cpu(), ref.detach(), what="gcndec loss", rtol=2e-5)
+    for i, (w, b) in enumerate(convs, 1):
+        assert_close(getattr(d.gcn, f"conv{i}").lin.weight.grad.cpu(), w.grad, what=f"conv{i}.w", rtol=2e-5, atol_scale=1e-5)
+        assert_close(getattr(d.gcn, f"conv{i}").bias.grad.cpu(), b.grad, what=f"conv{i}.b", rtol=2e-5, atol_scale=1e-5)
+    for i, (w, b) in enumerate(fcs, 1):
+        assert_close(getattr(d.gcn, f"fc{i}").weight.grad.cpu(), w.grad, what=f"fc{i}.w", rtol=2e-5, atol_scale=1e-5)
+        assert_close(getattr(d.gcn, f"fc{i}").bias.grad.cpu(), b.grad, what=f"fc{i}.b", rtol=2e-5, atol_scale=1e-5)
+    # one sampling step through the gcndec denoiser
+    d.eval()
+    with torch.no_grad():
+        direction = d.directions(torch.from_numpy(case["u0"]).cuda())
+        pred, x0 = d.p_sample(torch.from_numpy(case["img"]).cuda(), None, adj, direction, case["labels"],
+                              torch.from_numpy(case["u0"]).cuda(), 150, None, False)
+        x0_ref = ogcn.gcndec(torch.from_numpy(case["img"]), ei, torch.full((n,), 150.0, dtype=torch.float64), convs, fcs)
+    assert_close(x0.cpu(), x0_ref.clamp(-1, 1), what="gcndec p_sample x0", atol_scale=1e-5,
+                 scale=float(x0_ref.abs().max()))
+    assert pred.shape == (n, dim) and bool(torch.isfinite(pred).all())
