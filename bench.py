@@ -58,9 +58,17 @@ def build_workload(dim, T, seed, device):
                 nnz=idx.shape[1], host=host, feat=feat + 1)
 
 
-def one_step(w, t):
+def one_step(w, t, ev=None):
+    if ev is not None:
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
     h = w["enc"].encode(w["x"], w["adj"])
+    if ev is not None:
+        e[1].record()
     pred, x0 = w["diff"].p_sample(w["img"], None, 1, w["direction"], w["labels"], w["u0"], t, None, True)
+    if ev is not None:
+        e[2].record()
+        ev.append(e)
     return h, pred
 
 
@@ -165,9 +173,10 @@ def main():
             one_step(w, T - 1 - (i % T))
         barrier()
         ops.GEMM_EVENTS = []
+        phase = []
         t0 = time.perf_counter()
         for i in range(a.steps):
-            one_step(w, T - 1 - (i % T))
+            one_step(w, T - 1 - (i % T), phase)
         barrier()
         elapsed = time.perf_counter() - t0
         events, ops.GEMM_EVENTS = ops.GEMM_EVENTS, None
@@ -209,6 +218,12 @@ def main():
                      "gemm_ms_per_step": gemm_ms / a.steps,
                      "memory_bound_kernels": "profiles/r01_kernel_roofline.jsonl (tools/bench_kernels.py)"},
     }
+    enc_ms = sum(e[0].elapsed_time(e[1]) for e in phase) / max(1, len(phase))
+    dif_ms = sum(e[1].elapsed_time(e[2]) for e in phase) / max(1, len(phase))
+    out["breakdown"] = {"encode_ms": enc_ms, "encode_nodes_per_s_per_gpu": w["n"] / (enc_ms * 1e-3) if enc_ms else None,
+                        "p_sample_ms": dif_ms,
+                        "ddpm_node_steps_per_s_per_gpu": w["n"] / (dif_ms * 1e-3) if dif_ms else None,
+                        "note": "HIP-event time of the two phases of one step on rank 0 (SURVEY.md 8d)"}
     if a.train_steps > 0:
         try:
             out["train"] = train_leg(w, a.dim, device, a.train_steps, 3, barrier, dist)

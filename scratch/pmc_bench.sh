@@ -1,7 +1,10 @@
 #!/bin/bash
+# HBM traffic counters of bench.py: one rocprofv3 --pmc pass per counter (FETCH_SIZE takes 3 of the 4
+# TCC slots, WRITE_SIZE 2), kernel trace only.
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_bench_$c
-  mkdir -p $OUT
-  timeout -s KILL 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/log.txt 2>&1 || exit 1
+  rm -rf $OUT; mkdir -p $OUT
+  timeout -s KILL 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --train-steps 0 > $OUT/log.txt 2>&1 || exit 1
 done
+python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $GRAFT_REPO_ROOT/gpurun_out/pmc_bench_FETCH_SIZE $GRAFT_REPO_ROOT/gpurun_out/pmc_bench_WRITE_SIZE > $GRAFT_REPO_ROOT/gpurun_out/bench_hbm_traffic.json
