@@ -362,3 +362,47 @@ def test_hip_gcndec_vs_oracle():
     assert_close(x0.cpu(), x0_ref.clamp(-1, 1), what="gcndec p_sample x0", atol_scale=1e-5,
                  scale=float(x0_ref.abs().max()))
     assert pred.shape == (n, dim) and bool(torch.isfinite(pred).all())
+
+
+# ------------------------------------------------------------------ training GEMM forms, raw
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,P,Q", [(1, 4, 4), (31, 8, 132), (64, 128, 128), (257, 900, 516), (1000, 14, 17),
+                                   (5000, 260, 68), (15777, 64, 512)])
+def test_hip_gemm_tn_shapes(R, P, Q):
+    """dW = A^T B over ragged slice / tile boundaries, exact on small-integer data (fp32 sums of
+    integers below 2^24 are exact in any order) and within fp32 reassociation on Gaussian data."""
+    from hypdiff_amd import autograd as hag
+    rs = np.random.RandomState(R + P + Q)
+    a = rs.randint(-3, 4, size=(R, P)).astype(np.float32)
+    b = rs.randint(-3, 4, size=(R, Q)).astype(np.float32)
+    got = hag.gemm_tn(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    assert np.array_equal(got.cpu().numpy(), (a.astype(np.float64).T @ b.astype(np.float64)).astype(np.float32))
+    a, b = rs.standard_normal((R, P)).astype(np.float32), rs.standard_normal((R, Q)).astype(np.float32)
+    got = hag.gemm_tn(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    want = a.astype(np.float64).T @ b.astype(np.float64)
+    bound = 2e-6 * (np.abs(a).astype(np.float64).T @ np.abs(b).astype(np.float64))
+    assert (np.abs(got.cpu().numpy() - want) <= bound + 1e-30).all()
+
+
+@pytest.mark.gpu
+def test_hip_dgrad_epilogue_transpose_colsum():
+    from hypdiff_amd import autograd as hag
+    rs = np.random.RandomState(2)
+    M, N, K = 333, 70, 52
+    dz = torch.from_numpy(rs.standard_normal((M, N)).astype(np.float32)).cuda()
+    w = torch.from_numpy(rs.standard_normal((N, K)).astype(np.float32)).cuda()
+    z = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32)).cuda()
+    resid = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32)).cuda()
+    wt = hag.transpose(w)
+    assert torch.equal(wt, w.t().contiguous())
+    g, dzb = torch.empty(M, K, device="cuda"), torch.empty(M, K, device="cuda")
+    hag.gemm_ex(dz, wt, None, resid, z, g, dzb, 3)
+    g64 = dz.double().cpu() @ w.double().cpu() + resid.double().cpu()
+    zz = z.double().cpu().requires_grad_()
+    torch.nn.functional.gelu(zz).sum().backward()
+    assert_close(g.cpu(), g64, what="dgrad g", atol_scale=3e-6)
+    assert_close(dzb.cpu(), g64 * zz.grad, what="dgrad dz", atol_scale=3e-6)
+    assert_close(hag.colsum(dz).cpu(), dz.double().cpu().sum(0), what="colsum", atol_scale=3e-6)
+    big = torch.from_numpy(rs.standard_normal((20000, 33)).astype(np.float32)).cuda()
+    assert_close(hag.colsum(big).cpu(), big.double().cpu().sum(0), what="colsum big", atol_scale=1e-5,
+                 scale=float(big.abs().sum(0).max()))
