@@ -104,12 +104,28 @@ __global__ __launch_bounds__(256) void pack_input_k(const TX* __restrict__ x, co
 
 constexpr int kMomentBlocks = 1024;
 
+// 16-byte loads, four independent fp64 accumulator pairs per lane (the fixed element -> lane ->
+// block assignment keeps the reduction tree, hence the bits, reproducible)
 template <typename TX>
 __global__ __launch_bounds__(256) void moments_partial_k(const TX* __restrict__ x, int64_t count,
                                                          double* __restrict__ ws) {
+    constexpr int V = 16 / sizeof(TX);
+    using VT = typename VecOf<TX>::type;
     __shared__ double s1[4], s2[4];
     double a = 0.0, b = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+    const int64_t nvec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? count / V : 0;
+    const VT* xv = reinterpret_cast<const VT*>(x);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const VT t = xv[i];
+        const TX* tp = reinterpret_cast<const TX*>(&t);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const double v = (double)tp[e];
+            a += v;
+            b += v * v;
+        }
+    }
+    for (int64_t i = nvec * V + (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
         const double v = (double)x[i];
         a += v;
         b += v * v;
@@ -144,13 +160,27 @@ __global__ __launch_bounds__(256) void moments_final_k(const double* __restrict_
 template <typename TX>
 __global__ __launch_bounds__(256) void standardize_k(const TX* __restrict__ x, TX* __restrict__ out, int64_t count,
                                                      const double* __restrict__ m, int inverse) {
+    constexpr int V = 16 / sizeof(TX);
+    using VT = typename VecOf<TX>::type;
     const double n = m[2], mean = m[0] / n;
     const double var = (m[1] - m[0] * m[0] / n) / (n - 1.0);
     const double sd = sqrt(var > 0.0 ? var : 0.0);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
-        const double v = (double)x[i];
-        out[i] = (TX)(inverse ? v * sd + mean : (v - mean) / sd);
+    // one multiply-add per element in fp64: (v - mean) / sd = v * (1/sd) - mean/sd up to 1 ulp of fp64
+    const double mul = inverse ? sd : 1.0 / sd;
+    const double add = inverse ? mean : -mean / sd;
+    const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    const int64_t nvec = al ? count / V : 0;
+    const VT* xv = reinterpret_cast<const VT*>(x);
+    VT* ov = reinterpret_cast<VT*>(out);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        VT t = xv[i];
+        TX* tp = reinterpret_cast<TX*>(&t);
+#pragma unroll
+        for (int e = 0; e < V; ++e) tp[e] = (TX)fma((double)tp[e], mul, add);
+        ov[i] = t;
     }
+    for (int64_t i = nvec * V + (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+        out[i] = (TX)fma((double)x[i], mul, add);
 }
 
 // ---- graph-level latent DDPM (ddpm.py / ddpm_utils.py), fp32 throughout -----------------
