@@ -30,6 +30,7 @@ SIZE_QUERIES = {
     "hd_gemm_tn_workspace_floats": [I64, I64, I64],
     "hd_colsum_workspace_floats": [I64, I64],
     "hd_mse_workspace_doubles": [],
+    "hd_hkm_workspace_doubles": [I64, I64, I64],
 }
 
 # name -> argtypes; names ending in "*" exist as _f32 and _f64
@@ -79,6 +80,10 @@ SIGNATURES = {
     "hd_ddpm_noise": [P, P, P, P, I64, P, I64, I64, c_int, c_double, c_double, c_double, P],
     "hd_ddpm_step": [P, P, P, c_double, c_double, c_double, P, I64, P],
     "hd_embedding_add": [P, P, P, I64, I64, I64, P],
+    "hd_hkm_to_hyperboloid": [P, P, I64, I64, P],
+    "hd_hkm_mean_step": [P, P, P, I64, I64, I64, c_double, P, P],
+    "hd_hkm_to_poincare": [P, P, I64, I64, P],
+    "hd_hkm_assign": [P, P, P, P, I64, I64, I64, P],
     "hd_standardize": [P, P, c_int, I64, P, c_int, P],
 }
 

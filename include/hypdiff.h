@@ -266,6 +266,24 @@ int hd_ddpm_step(const float* x, const float* eps, const float* noise, double c1
 int hd_embedding_add(float* h, const float* table, const int64_t* idx, int64_t T, int64_t rows, int64_t dim,
                      void* stream);
 
+/* ---- hyperbolic k-means (labels / centres u0 between encode and diffusion), fp64 -------------
+ * hyperbolic_learning/hyperbolic_kmeans/hkmeans.py + util_hk.py.  Hyperboloid rows carry the
+ * time coordinate LAST, as util_hk.py does. */
+/* poincare_pts_to_hyperboloid util_hk.py:28-61: y (rows, dim) -> h (rows, dim+1) */
+int hd_hkm_to_hyperboloid(const double* y, double* h, int64_t rows, int64_t dim, void* stream);
+/* one round of compute_mean hkmeans.py:56-70 for all K centres at once: theta (K, dim+1) is
+ * updated in place from the members (labels int32 (rows,)) of each cluster; a cluster without
+ * members keeps its centre.  workspace: hd_hkm_workspace_doubles(rows, dim, K) doubles. */
+int64_t hd_hkm_workspace_doubles(int64_t rows, int64_t dim, int64_t K);
+int hd_hkm_mean_step(const double* h, const int32_t* labels, double* theta, int64_t rows, int64_t dim, int64_t K,
+                     double alpha, double* workspace, void* stream);
+/* hyperboloid_pt_to_poincare util_hk.py:118-133 (+ proj :112-115): theta (K, dim+1) -> (K, dim) */
+int hd_hkm_to_poincare(const double* theta, double* centres, int64_t K, int64_t dim, void* stream);
+/* assignment step hkmeans.py:206-214: labels[i] = argmin_k poincare_dist(x_i, centre_k)
+ * (util_hk.py:14-16); dist2 (optional) = that distance squared (the inertia terms) */
+int hd_hkm_assign(const double* x, const double* centres, int32_t* labels, double* dist2, int64_t rows,
+                  int64_t dim, int64_t K, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

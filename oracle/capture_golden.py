@@ -477,6 +477,32 @@ def capture_train(out_dir):
     print("train", len(store), "arrays")
 
 
+def capture_kmeans(out_dir):
+    """HyperbolicKMeans.fit of the reference (hyperkmeans.py:42-44: k=3, max_epochs=5) on embeddings
+    inside the unit ball; numpy's global generator is seeded and its two initialisation draws
+    are replayed into the fixture."""
+    from hyperbolic_learning.hyperbolic_kmeans.hkmeans import HyperbolicKMeans
+    store = {}
+    for tag, n, d, seed in (("n60d16", 60, 16, 7), ("n150d2", 150, 2, 11), ("n90d65", 90, 65, 3)):
+        rs = np.random.RandomState(100 + n)
+        X = rs.standard_normal((n, d)) * (0.6 / np.sqrt(d))
+        X[: n // 3] += 0.35 / np.sqrt(d)
+        X[n // 3: 2 * n // 3] -= 0.3 / np.sqrt(d)
+        if tag == "n150d2":
+            X *= 1.6                                 # some rows outside the ball: exercises the rescale
+        np.random.seed(seed)
+        init_c = np.random.uniform(0, 0.3, size=(3, d))
+        init_l = np.array([np.random.randint(0, 3) for _ in range(n)])
+        np.random.seed(seed)
+        km = HyperbolicKMeans(n_clusters=3)
+        cen, lab = km.fit(X.copy(), max_epochs=5)
+        store[tag + "/X"], store[tag + "/init_centroids"], store[tag + "/init_labels"] = X, init_c, init_l
+        store[tag + "/centroids"], store[tag + "/labels"] = cen, lab
+        store[tag + "/seed"] = np.array(seed)
+    np.savez_compressed(os.path.join(out_dir, "kmeans.npz"), **store)
+    print("kmeans", len(store), "arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
@@ -498,6 +524,8 @@ def main():
         capture_ddpm(out)
     if a.only in ("", "train"):
         capture_train(out)
+    if a.only in ("", "kmeans"):
+        capture_kmeans(out)
 
 
 if __name__ == "__main__":
