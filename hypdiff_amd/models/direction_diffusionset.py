@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import autograd as hag
 from .. import ops
 from . import direction_diffusion as dd
 
@@ -127,7 +128,8 @@ class diffusionset(dd.diffusion):
         return ops.map_at("hd_pb_expmap_at", cen, lab, ret.reshape(g * n, d), 1.0).view(g, n, d)
 
     def forward(self, x, adj, labels, u0, restrict=False, graphset=False, t=None, noise=None):
-        """:354-384 (forward value of the training loss)"""
+        """:354-384 training loss; differentiable w.r.t. the denoiser parameters (HIP backward
+        kernels, hypdiff_amd/autograd.py) -- the loss diff.hyperdiff_graphset trains (diff.py:230-260)"""
         if not graphset:
             raise NotImplementedError("gcndec denoiser not built; use graphset=True")
         x = x.to(torch.float64)
@@ -142,4 +144,5 @@ class diffusionset(dd.diffusion):
         x_start = self.normalization(x_start)
         xt = self.q_sample(x_start=x_start, t=t, direction=direction, noise=noise, labels=labels, u0=u0, restrict=True)
         out = self.mlp(xt, t / self.num_timesteps)
-        return F.mse_loss(out, x_start.to(torch.float32))
+        target = x_start.to(torch.float32)
+        return hag.mse_loss(out.reshape(-1, out.shape[-1]), target.reshape(-1, target.shape[-1]))

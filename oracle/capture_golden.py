@@ -441,6 +441,21 @@ def capture_train(out_dir):
     store["ddpm/loss"] = N(loss)
     for name, p_ in model.named_parameters():
         store["ddpm/grad/" + name] = N(p_.grad)
+    # graph-set node-level diffusion (diff.py:230-260 trains diffusionset.forward): inputs of diffusionset.npz
+    import models.direction_diffusionset as dset
+    gs = np.load(os.path.join(out_dir, "diffusionset.npz"))
+    torch.manual_seed(1432)
+    dsm = dset.diffusionset(types.SimpleNamespace(r=2.0, t=1.0), 14, 14).train()
+    load_mlp(dsm, 14)
+    tt, nz = T(gs["c/t"]), T(gs["c/noise"])
+    with injected(randint=lambda *a, **k: tt.clone(), randn_like=lambda *a, **k: nz.clone()):
+        loss = dsm(T(gs["c/x"]).clone(), 1, gs["c/labels"], T(gs["c/u0"]), restrict=True, graphset=True)
+    loss.backward()
+    store["diffusionset/loss"] = N(loss)
+    for name in ("fc1.weight", "fc1.bias", "fc5.weight", "fc5.bias", "fc3.bias"):
+        mod, attr = name.split(".")
+        store["diffusionset/grad/" + name] = N(getattr(getattr(dsm.mlp, mod), attr).grad)
+
     # HGCN encoder (lp_train.py:66-82 trains it through loss.backward()): gradients of
     # sum(encode(x) * G) w.r.t. the two HypLinear weights, G a fixed Gaussian; models, graphs and
     # weights are those of layers.npz (same seeds), so only G-seed-derived outputs are stored

@@ -85,3 +85,25 @@ def test_hip_diffusionset_golden(golden):
         ret = d.p_sample_loop(x, 1, labels, u0, graphset=True, img=C("c/img"))
         assert_close(x.cpu(), g["p_sample_loop/x_after"], what="x mutated")
         assert_close(ret.cpu(), g["p_sample_loop/ret"], rtol=1e-3, atol_scale=1e-4, what="loop")
+
+
+@pytest.mark.gpu
+def test_hip_diffusionset_training_grads(golden):
+    """diffusionset.forward + loss.backward() (the loss of diff.hyperdiff_graphset, diff.py:230-260)
+    against the reference's own gradients"""
+    import types
+    from hypdiff_amd.models.direction_diffusionset import diffusionset
+    g, gt = golden("diffusionset"), golden("train")
+    d = diffusionset(types.SimpleNamespace(r=2.0, t=1.0), D, D).train()
+    sd = {}
+    for i, (w, b) in enumerate(gi.mlp_params(D), 1):
+        sd[f"fc{i}.weight"], sd[f"fc{i}.bias"] = torch.from_numpy(w), torch.from_numpy(b)
+    d.mlp.load_state_dict(sd)
+    C = lambda k: torch.from_numpy(np.array(g[k])).cuda()
+    loss = d(C("c/x"), 1, g["c/labels"], C("c/u0"), restrict=True, graphset=True, t=C("c/t"), noise=C("c/noise"))
+    loss.backward()
+    assert_close(loss.detach().cpu(), gt["diffusionset/loss"], what="loss")
+    for name in ("fc1.weight", "fc1.bias", "fc5.weight", "fc5.bias", "fc3.bias"):
+        mod, attr = name.split(".")
+        assert_close(getattr(getattr(d.mlp, mod), attr).grad.cpu(), gt["diffusionset/grad/" + name], what=name,
+                     rtol=1e-5, atol_scale=2e-6)
