@@ -31,6 +31,7 @@ SIZE_QUERIES = {
     "hd_colsum_workspace_floats": [I64, I64],
     "hd_mse_workspace_doubles": [],
     "hd_hkm_workspace_doubles": [I64, I64, I64],
+    "hd_limb_image_bytes": [I64, I64],
 }
 
 # name -> argtypes; names ending in "*" exist as _f32 and _f64
@@ -63,6 +64,10 @@ SIGNATURES = {
     "hd_gemm_f32": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, c_int, P],
     "hd_gemm_f64": [P, P, P, P, I64, I64, I64, I64, I64, I64, P],
     "hd_gemm_f32_ex": [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, c_int, P],
+    "hd_gemm_f32_bf16x3": [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, c_int, P],
+    "hd_limb_pack_f32": [P, I64, I64, I64, P, P],
+    "hd_limb_unpack_f32": [P, I64, I64, P, I64, P],
+    "hd_gemm_limbs_f32": [P, P, P, P, P, P, I64, I64, I64, I64, c_int, P],
     "hd_gemm_tn_f32": [P, P, P, I64, I64, I64, I64, I64, I64, P, P],
     "hd_transpose_f32": [P, P, I64, I64, I64, I64, P],
     "hd_colsum_f32": [P, P, I64, I64, I64, P, P],

@@ -27,7 +27,7 @@ def _ws(n, dtype, device):
 
 
 def gemm_ex(a, w, bias, resid, aux, c, c2, epi):
-    """hd_gemm_f32_ex on fp32 device tensors; a (M,K), w (N,K); c / c2 may be None."""
+    """hd_gemm_f32_ex / hd_gemm_f32_bf16x3 (ops.GEMM_MODE) on fp32 device tensors; a (M,K), w (N,K); c / c2 may be None."""
     M, K = a.shape
     N = w.shape[0]
     if K % 4 or a.stride(0) % 4 or w.stride(0) % 4 or a.data_ptr() % 16 or w.data_ptr() % 16 or a.stride(1) != 1 \
@@ -39,7 +39,7 @@ def gemm_ex(a, w, bias, resid, aux, c, c2, epi):
     if ev is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.call("hd_gemm_f32_ex", ops._p(a), ops._p(w), ops._p(bias), ops._p(resid), ops._p(aux), ops._p(c), ops._p(c2),
+    _lib.call(ops.gemm_symbol(), ops._p(a), ops._p(w), ops._p(bias), ops._p(resid), ops._p(aux), ops._p(c), ops._p(c2),
               M, N, a.shape[1], a.stride(0), w.stride(0), ref.stride(0), epi, ops._stream())
     if ev is not None:
         e1.record()

@@ -34,15 +34,9 @@ class MLP(nn.Module):
                 x = ops._pad_k(x, (x.shape[1] + 3) // 4 * 4)
             kinds = (hag.GELU,) + (hag.RES,) * (last - 1) + (hag.LIN,)
             return hag.linear_stack(x, list(self.layers), kinds)
-        for idx, layer in enumerate(self.layers):
-            w, b = layer.weight.detach(), layer.bias.detach()
-            if idx == 0:
-                x = ops.gemm(x, w, b, epi=1)                       # gelu(layer(x))
-            elif idx == last:
-                x = ops.gemm(x, w, b, epi=0)
-            else:
-                x = ops.gemm(x, w, b, epi=2, resid=x)              # x0 + gelu(layer(x0))
-        return x
+        # gelu(layer(x)) first, x0 + gelu(layer(x0)) in between, plain layer last
+        return ops.linear_chain(x, [(layer.weight, layer.bias, 1 if idx == 0 else (0 if idx == last else 2))
+                                    for idx, layer in enumerate(self.layers)])
 
 
 class Backbone(nn.Module):

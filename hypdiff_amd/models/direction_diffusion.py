@@ -121,9 +121,8 @@ class gcndec(nn.Module):
             h = hag.GCNConvGelu.apply(h, conv.lin.weight, conv.bias, csr, True)
         if hag.wants_grad(h, *self.parameters()):
             return hag.linear_stack(h, [self.fc1, self.fc2, self.fc3], (hag.GELU, hag.GELU, hag.LIN))
-        h = ops.gemm(h, self.fc1.weight.detach(), self.fc1.bias.detach(), epi=1)
-        h = ops.gemm(h, self.fc2.weight.detach(), self.fc2.bias.detach(), epi=1)
-        return ops.gemm(h, self.fc3.weight.detach(), self.fc3.bias.detach(), epi=0)
+        return ops.linear_chain(h, [(self.fc1.weight, self.fc1.bias, 1), (self.fc2.weight, self.fc2.bias, 1),
+                                    (self.fc3.weight, self.fc3.bias, 0)])
 
 
 class mlp(nn.Module):
@@ -167,11 +166,14 @@ class mlp(nn.Module):
             # training (diff.py:113-118): forward and backward on HIP kernels, autograd only links them
             return hag.linear_stack(h, [self.fc1, self.fc2, self.fc3, self.fc4, self.fc5],
                                     (hag.GELU, hag.GELU, hag.GELU, hag.GELU, hag.LIN))
-        h = ops.gemm(h, self._w1(ld), self.fc1.bias.detach(), epi=1)
-        h = ops.gemm(h, self.fc2.weight.detach(), self.fc2.bias.detach(), epi=1)
-        h = ops.gemm(h, self.fc3.weight.detach(), self.fc3.bias.detach(), epi=1)
-        h = ops.gemm(h, self.fc4.weight.detach(), self.fc4.bias.detach(), epi=1)
-        return ops.gemm(h, self.fc5.weight.detach(), self.fc5.bias.detach(), epi=0)
+        if ops.GEMM_MODE == "exact":
+            h1 = ops.gemm(h, self._w1(ld), self.fc1.bias.detach(), epi=1)
+        else:
+            h, h1 = h[:, : d + 1], None
+        return ops.linear_chain(h if h1 is None else h1,
+                                ([(self.fc1.weight, self.fc1.bias, 1)] if h1 is None else []) +
+                                [(self.fc2.weight, self.fc2.bias, 1), (self.fc3.weight, self.fc3.bias, 1),
+                                 (self.fc4.weight, self.fc4.bias, 1), (self.fc5.weight, self.fc5.bias, 0)])
 
 
 def get_alphas(timesteps):

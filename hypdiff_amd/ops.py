@@ -5,6 +5,7 @@ enqueues HIP kernels of libhypdiff_hip.so on the current stream and returns with
 synchronising.  Inputs must live on the GPU; nothing here computes on the CPU.
 """
 import ctypes
+import os
 import weakref
 
 import numpy as np
@@ -17,6 +18,17 @@ ACT_CODES = {"identity": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "elu": 4, "leaky
 
 _curv_cache = {}
 GEMM_EVENTS = None      # set to a list by bench.py to time every hd_gemm_f32 launch
+# fp32 GEMM kernel: "bf16x3" = fp32-accurate 3-limb split on the bf16 matrix cores (6 MFMAs per
+# product term, csrc/gemm_split.hip); "exact" = v_mfma_f32_32x32x2_f32 (csrc/gemm.hip).
+GEMM_MODE = os.environ.get("HD_GEMM_MODE", "bf16x3")
+
+
+def gemm_symbol():
+    if GEMM_MODE == "bf16x3":
+        return "hd_gemm_f32_bf16x3"
+    if GEMM_MODE == "exact":
+        return "hd_gemm_f32_ex"
+    raise ValueError("hypdiff_amd.ops.GEMM_MODE must be 'bf16x3' or 'exact', not %r" % (GEMM_MODE,))
 
 
 def curv(c):
@@ -181,12 +193,109 @@ def gemm(a, w, bias=None, epi=0, resid=None, out=None):
     if ev is not None:          # bench.py: live HIP-event timing of the dominant kernel
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.call("hd_gemm_f32", _p(a), _p(w), _p(bias), _p(resid), _p(out), M, N, a.shape[1], a.stride(0),
+    _lib.call(gemm_symbol(), _p(a), _p(w), _p(bias), _p(resid), None, _p(out), None, M, N, a.shape[1], a.stride(0),
               w.stride(0), out.stride(0), epi, _stream())
     if ev is not None:
         e1.record()
         ev.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)))
     return out
+
+
+# ---- limb images: fp32 operands pre-split into 3 bf16 limbs (csrc/gemm_limbs.hip) ------------
+class LimbImage:
+    """A (rows, cols) fp32 matrix stored as its bf16 limb image (include/hypdiff.h)."""
+
+    __slots__ = ("buf", "rows", "cols")
+
+    def __init__(self, buf, rows, cols):
+        self.buf, self.rows, self.cols = buf, rows, cols
+
+
+def limb_empty(rows, cols, device):
+    nbytes = _lib.load().hd_limb_image_bytes(rows, cols)
+    return LimbImage(torch.empty(max(nbytes // 4, 4), dtype=torch.int32, device=device), rows, cols)
+
+
+def limb_pack(x):
+    """fp32 (rows, cols) row-major (any row stride) -> LimbImage."""
+    _dev(x)
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1
+    img = limb_empty(x.shape[0], x.shape[1], x.device)
+    _lib.call("hd_limb_pack_f32", _p(x), x.stride(0), x.shape[0], x.shape[1], _p(img.buf), _stream())
+    return img
+
+
+def limb_unpack(img):
+    out = torch.empty(img.rows, img.cols, dtype=torch.float32, device=img.buf.device)
+    _lib.call("hd_limb_unpack_f32", _p(img.buf), img.rows, img.cols, _p(out), out.stride(0), _stream())
+    return out
+
+
+_wlimb_cache = {}
+
+
+def weight_limbs(w):
+    """LimbImage of a weight matrix, rebuilt when the parameter changes (keyed like `curv`)."""
+    hit = _wlimb_cache.get(id(w))
+    if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == w.data_ptr():
+        return hit[3]
+    wd = w.detach()
+    img = limb_pack(wd if wd.stride(1) == 1 else wd.contiguous())
+    if len(_wlimb_cache) > 256:
+        _wlimb_cache.clear()
+    _wlimb_cache[id(w)] = (weakref.ref(w), w._version, w.data_ptr(), img)
+    return img
+
+
+def gemm_limbs(a, w, bias=None, epi=0, resid=None, want_f32=True, want_limbs=False, out=None):
+    """epi(a @ w.T + bias) from limb images; returns (fp32 tensor or None, LimbImage or None)."""
+    M, K, N = a.rows, a.cols, w.rows
+    assert w.cols == K, ((a.rows, a.cols), (w.rows, w.cols))
+    dev = a.buf.device
+    c = None
+    if want_f32:
+        c = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=dev)
+    cl = limb_empty(M, N, dev) if want_limbs else None
+    ldc = c.stride(0) if c is not None else (resid.stride(0) if resid is not None else N)
+    if resid is not None and c is not None:
+        assert resid.stride(0) == c.stride(0)
+    ev = GEMM_EVENTS
+    if ev is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.call("hd_gemm_limbs_f32", _p(a.buf), _p(w.buf), _p(bias), _p(resid), _p(c), _p(cl.buf) if cl else None,
+              M, N, K, ldc, epi, _stream())
+    if ev is not None:
+        e1.record()
+        ev.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)))
+    return c, cl
+
+
+def linear_chain(x, layers):
+    """Inference-only stack of nn.Linear layers: layers = [(weight, bias, epi), ...] with epi 0
+    none, 1 erf-GELU, 2 x + GELU(layer(x)) (ddpm.py:20-22); x fp32 (M, K) on the device.
+
+    GEMM_MODE "bf16x3": activations travel between layers as limb images written by the
+    previous GEMM's epilogue (split once per element), weights are split once per parameter
+    version; fp32 copies are written only where a residual or the caller needs them.
+    GEMM_MODE "exact": one hd_gemm_f32_ex per layer."""
+    _dev(x)
+    if GEMM_MODE != "bf16x3":
+        gemm_symbol()
+        h = x
+        for w, b, epi in layers:
+            h = gemm(h, w.detach(), None if b is None else b.detach(), epi=epi, resid=h if epi == 2 else None)
+        return h
+    a, xf = limb_pack(x), x
+    for i, (w, b, epi) in enumerate(layers):
+        last = i == len(layers) - 1
+        need_f32 = last or layers[i + 1][2] == 2
+        resid = None
+        if epi == 2:
+            resid = xf if xf.is_contiguous() else xf.contiguous()
+        xf, a = gemm_limbs(a, weight_limbs(w), None if b is None else b.detach(), epi=epi, resid=resid,
+                           want_f32=need_f32, want_limbs=not last)
+    return xf
 
 
 # ---- adjacency -------------------------------------------------------------------

@@ -189,6 +189,31 @@ int hd_gemm_f32(const void* A, const void* W, const void* bias, const void* resi
 int hd_gemm_f32_ex(const void* A, const void* W, const void* bias, const void* resid, const void* aux, void* C,
                    void* C2, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int epi,
                    void* stream);
+/* Same contract as hd_gemm_f32_ex (operands, epilogues, alignment rules), evaluated on the bf16
+ * matrix cores with fp32 accuracy: every fp32 operand is split exactly into three bf16 limbs and
+ * each product is the sum of the six limb products of weight >= 2^-16, accumulated in fp32
+ * (dropped terms < 2^-26 |a||w|, below one fp32 rounding).  6/16 of the exact-f32 MFMA time.
+ * Replaces the same reference lines as hd_gemm_f32 (manifolds/poincare.py:96,
+ * manifolds/hyperboloid.py:122, models/direction_diffusion.py:56-69, ddpm.py:17-27). */
+int hd_gemm_f32_bf16x3(const void* A, const void* W, const void* bias, const void* resid, const void* aux, void* C,
+                       void* C2, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int epi,
+                       void* stream);
+/* ---- the same contraction with operands pre-split into bf16 limbs ("limb images") ----
+ * Limb image of a (rows, cols) fp32 matrix: 16-byte chunks of 8 bf16,
+ *   chunk(rb, s, l, kc, r) = (((rb*nslab + s)*3 + l)*4 + kc)*128 + r,
+ * rb = row/128, r = row%128, s = col/32, kc = (col%32)/8, l = limb (h, m, l), nslab =
+ * ceil(cols/32); zero columns up to the slab boundary.  hd_limb_image_bytes gives the size.
+ * hd_limb_pack_f32 builds it from row-major fp32 (weights: once per parameter version; inputs),
+ * hd_limb_unpack_f32 sums the limbs back (tests).  hd_gemm_limbs_f32: A, W limb images of
+ * (M,K) and (N,K); C = epi(A W^T + bias) as fp32 row-major (C, ldc) and/or as the limb image
+ * of an (M,N) matrix (CL) that the next layer consumes directly; epi 0 none, 1 erf-GELU,
+ * 2 resid + GELU (resid fp32 row-major, ldc).  Staging is a linear LDS-DMA copy; no split work
+ * inside the contraction.  Same reference lines as hd_gemm_f32. */
+int64_t hd_limb_image_bytes(int64_t rows, int64_t cols);
+int hd_limb_pack_f32(const void* in, int64_t ld, int64_t rows, int64_t cols, void* out, void* stream);
+int hd_limb_unpack_f32(const void* in, int64_t rows, int64_t cols, void* out, int64_t ld, void* stream);
+int hd_gemm_limbs_f32(const void* A, const void* W, const void* bias, const void* resid, void* C, void* CL,
+                      int64_t M, int64_t N, int64_t K, int64_t ldc, int epi, void* stream);
 /* Weight gradient dW[P,Q] = A[R,P]^T @ B[R,Q] (A = dL/dz, B = layer input; autograd of
  * F.linear, models/direction_diffusion.py:56-69).  The R rows are split over workgroups and
  * the partial tiles summed in slice order (bit-reproducible).  P, Q, lda, ldb multiples of 4;
