@@ -38,9 +38,12 @@ def test_oracle_ddpm_golden(golden):
 
 
 @pytest.mark.gpu
-def test_hip_ddpm_golden(golden):
+@pytest.mark.parametrize("gemm_mode", ["bf16x3", "exact"])
+def test_hip_ddpm_golden(golden, gemm_mode, monkeypatch):
+    from hypdiff_amd import ops
     from hypdiff_amd.ddpm import Model
     from hypdiff_amd.ddpm_utils import DDPMSampler
+    monkeypatch.setattr(ops, "GEMM_MODE", gemm_mode)      # both fp32 GEMM kernels (24-layer limb chain)
     g = golden("ddpm")
     sd, _, _, _ = _parts(g)
     model = Model(D, Hd, L, Tn, 1e-4, 0.02).cuda().eval()

@@ -30,6 +30,18 @@ def _lib_loaded():
     assert torch.cuda.is_available()
 
 
+@pytest.fixture
+def gemm_mode(request):
+    """Run a test under one of the two fp32 GEMM kernels (ops.GEMM_MODE), then restore."""
+    from hypdiff_amd import ops
+    old, ops.GEMM_MODE = ops.GEMM_MODE, request.param
+    yield request.param
+    ops.GEMM_MODE = old
+
+
+BOTH_GEMMS = pytest.mark.parametrize("gemm_mode", ["bf16x3", "exact"], indirect=True)
+
+
 # ---------------------------------------------------------------------------------
 @pytest.mark.parametrize("mname", ["PoincareBall", "Hyperboloid"])
 @pytest.mark.parametrize("dt", ["f32", "f64"])
@@ -203,9 +215,10 @@ def test_layers_golden(golden, kind, n, mname, c):
                 assert_close(H(fused), g[k + f"L{i}/act"], rtol=2e-5, atol_scale=2e-6, what=k + f"L{i}/fused")
 
 
+@BOTH_GEMMS
 @pytest.mark.parametrize("kind,n", GRAPHS)
 @pytest.mark.parametrize("mname,c", [("PoincareBall", 0.6), ("Hyperboloid", 1.0)])
-def test_hgcn_encode_golden(golden, kind, n, mname, c):
+def test_hgcn_encode_golden(golden, kind, n, mname, c, gemm_mode):
     import types
     from hypdiff_amd.models.encoders import HGCN
     g = golden("layers")
@@ -241,7 +254,8 @@ def test_hgcn_encode_golden(golden, kind, n, mname, c):
 
 
 # ---------------------------------------------------------------------------------
-def test_gemm_vs_fp64():
+@BOTH_GEMMS
+def test_gemm_vs_fp64(gemm_mode):
     from hypdiff_amd import ops
     rs = np.random.RandomState(1)
     for (M, N, K) in [(1, 5, 8), (129, 700, 900), (300, 64, 516), (1000, 800, 65), (257, 130, 36)]:
@@ -308,7 +322,59 @@ def test_q_sample_golden(golden):
                 assert np.array_equal(H(nz), g[f"q_sample/{tag}/restrict{r}/noise_after"])
 
 
-def test_mlp_and_p_sample_golden(golden):
+def test_limb_images_and_limb_gemm():
+    """bf16 limb images (csrc/gemm_limbs.hip): exact round trip, fp32-accurate contraction from
+    pre-split operands, limb write-out equal to the fp32 write-out, residual epilogue, chains."""
+    from hypdiff_amd import ops
+    rs = np.random.RandomState(5)
+    x = rs.standard_normal((300, 70)).astype(np.float32) * np.exp(rs.standard_normal((300, 1)) * 8).astype(np.float32)
+    x[7] = 0.0
+    assert np.array_equal(H(ops.limb_unpack(ops.limb_pack(G(x)))), x)            # h + m + l is exact
+    xs = G(np.ascontiguousarray(np.pad(x, ((0, 0), (0, 6)))))[:, :70]             # strided rows
+    assert np.array_equal(H(ops.limb_unpack(ops.limb_pack(xs))), x)
+    for (M, N, K) in [(1, 5, 8), (129, 700, 900), (300, 64, 516), (1000, 800, 65), (257, 130, 36), (128, 64, 32)]:
+        ai = rs.randint(-4, 5, size=(M, K)).astype(np.float32)
+        wi = rs.randint(-4, 5, size=(N, K)).astype(np.float32)
+        got, _ = ops.gemm_limbs(ops.limb_pack(G(ai)), ops.limb_pack(G(wi)))
+        assert np.array_equal(H(got), ai @ wi.T)
+        # rows spanning 14 orders of magnitude: the error bar is relative to sum |a||w| per element
+        a = rs.standard_normal((M, K)).astype(np.float32) * np.exp(rs.standard_normal((M, 1)) * 8).astype(np.float32)
+        w = rs.standard_normal((N, K)).astype(np.float32)
+        b = rs.standard_normal(N).astype(np.float32)
+        ref = a.astype(np.float64) @ w.astype(np.float64).T + b
+        mag = np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64).T + np.abs(b)
+        al, wl = ops.limb_pack(G(a)), ops.limb_pack(G(w))
+        c, cl = ops.gemm_limbs(al, wl, G(b), want_f32=True, want_limbs=True)
+        assert np.all(np.abs(H(c) - ref) <= 2e-6 * mag), (M, N, K, (np.abs(H(c) - ref) / mag).max())
+        assert np.array_equal(H(ops.limb_unpack(cl)), H(c))                       # same values, two formats
+        gl, _ = ops.gemm_limbs(al, wl, G(b), epi=1)
+        want = torch.nn.functional.gelu(torch.from_numpy(ref)).numpy()
+        assert np.all(np.abs(H(gl) - want) <= 2e-6 * mag + 1e-30)
+        if True:
+            r = rs.standard_normal((M, N)).astype(np.float32)
+            gr, _ = ops.gemm_limbs(al, wl, G(b), epi=2, resid=G(r))
+            assert np.all(np.abs(H(gr) - (r + want)) <= 2e-6 * mag + 1e-6 * np.abs(r) + 1e-30)
+    # a chain (first layer gelu, residual layers, plain last layer; ddpm.py:17-27) in both modes
+    ws = [torch.from_numpy((rs.standard_normal(s) / np.sqrt(s[1])).astype(np.float32)).cuda()
+          for s in [(96, 68), (96, 96), (96, 96), (10, 96)]]
+    bs = [torch.from_numpy(rs.standard_normal(w.shape[0]).astype(np.float32)).cuda() for w in ws]
+    x0 = G(rs.standard_normal((333, 68)).astype(np.float32))
+    layers = [(w, b, e) for w, b, e in zip(ws, bs, (1, 2, 2, 0))]
+    h = x0.double()
+    for w, b, e in layers:
+        z = h @ w.double().T + b.double()
+        h = z if e == 0 else (torch.nn.functional.gelu(z) if e == 1 else h + torch.nn.functional.gelu(z))
+    old = ops.GEMM_MODE
+    try:
+        for mode in ("bf16x3", "exact"):
+            ops.GEMM_MODE = mode
+            assert_close(H(ops.linear_chain(x0, layers)), H(h), what="linear_chain " + mode, atol_scale=2e-6)
+    finally:
+        ops.GEMM_MODE = old
+
+
+@BOTH_GEMMS
+def test_mlp_and_p_sample_golden(golden, gemm_mode):
     g = golden("diffusion")
     d = _diff()
     u0 = G(g["c/u0"])
