@@ -25,8 +25,46 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MFMA_F32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix peak
+MFMA_F32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+MFMA_BF16_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 matrix peak
 HBM_PEAK_GBS = 8000.0
+# dense MFMA peak per ALGORITHMIC fp32 flop of each GEMM kernel: the limb kernels issue six bf16
+# MFMAs per fp32 product (csrc/gemm_limbs.hip, csrc/gemm_split.hip)
+GEMM_PEAKS = {"gemm_limbs": MFMA_BF16_PEAK_TFLOPS / 6, "gemm_f32_bf16x3": MFMA_BF16_PEAK_TFLOPS / 6,
+              "gemm_f32_mfma": MFMA_F32_PEAK_TFLOPS}
+GEMM_PMC_KEYS = {"gemm_limbs": "gemm_limbs", "gemm_f32_bf16x3": "gemm_f32_bf16x3", "gemm_f32_mfma": "gemm_f32_mfma"}
+
+
+def gemm_summary(events):
+    """Per GEMM kernel of the timed region: launches, HIP-event time, algorithmic flops / bytes."""
+    per = {}
+    for e in events:
+        d = per.setdefault(e[4], dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        d["launches"] += 1
+        d["ms"] += e[0].elapsed_time(e[1])
+        d["flops"] += e[2]
+        d["bytes"] += e[3]
+    return per
+
+
+def timed_steps(w, T, steps, warmup, barrier, ops, dist, device):
+    with torch.no_grad():
+        for i in range(warmup):
+            one_step(w, T - 1 - (i % T))
+        barrier()
+        ops.GEMM_EVENTS = []
+        phase = []
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one_step(w, T - 1 - (i % T), phase)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        events, ops.GEMM_EVENTS = ops.GEMM_EVENTS, None
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed, events, phase
 
 
 def build_workload(dim, T, seed, device):
@@ -143,6 +181,7 @@ def main():
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--timesteps", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact-leg", action="store_true", help="skip the comparison leg on the exact-f32 MFMA GEMM")
     ap.add_argument("--train-steps", type=int, default=20, help="steps of the secondary training leg (0 = skip)")
     a = ap.parse_args()
 
@@ -168,54 +207,54 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for i in range(a.warmup):
-            one_step(w, T - 1 - (i % T))
-        barrier()
-        ops.GEMM_EVENTS = []
-        phase = []
-        t0 = time.perf_counter()
-        for i in range(a.steps):
-            one_step(w, T - 1 - (i % T), phase)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        events, ops.GEMM_EVENTS = ops.GEMM_EVENTS, None
+    elapsed, events, phase = timed_steps(w, T, a.steps, a.warmup, barrier, ops, dist, device)
 
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # dominant kernel: the fp32 MFMA GEMM (denoiser + HypLinear); live HIP-event timing
-    flops = sum(e[2] for e in events)
-    gemm_ms = sum(e[0].elapsed_time(e[1]) for e in events)
-    achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    # HBM bytes per GEMM launch from the PMC passes of the same command (profiles/, collected
-    # with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE; cannot be sampled from inside the process)
+    # dominant kernel: the fp32 GEMM of the denoiser / HypLinear (live HIP-event timing per launch)
+    per = gemm_summary(events)
+    dom = max(per, key=lambda k: per[k]["ms"])
+    d = per[dom]
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+    peak = GEMM_PEAKS[dom]
+    # HBM bytes per launch from the PMC passes of the same command (profiles/, collected with
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE; cannot be sampled from inside the process)
     traffic, traffic_src = None, None
     tp = os.path.join(ROOT, "profiles", "r01_bench_hbm_traffic.json")
     if os.path.exists(tp):
         try:
-            traffic = json.load(open(tp))["kernels"]["gemm_f32_mfma<64>"]["hbm_bytes_corrected"]
-            traffic_src = "profiles/r01_bench_hbm_traffic.json (rocprofv3 PMC, per-launch mean)"
+            ks = json.load(open(tp))["kernels"]
+            hit = [v for k, v in ks.items() if k.startswith(GEMM_PMC_KEYS[dom])]
+            if hit:
+                traffic = int(sum(v["hbm_bytes_corrected"] * v["launches"] for v in hit) / sum(v["launches"] for v in hit))
+                traffic_src = "profiles/r01_bench_hbm_traffic.json (rocprofv3 PMC, per-launch mean)"
         except Exception:
             traffic = None
-    alg_bytes = sum(e[3] for e in events) / max(1, len(events))
+    gemm_ms = sum(v["ms"] for v in per.values())
     rows_total = w["n"] * a.steps * world
     out = {
         "metric": "latent node-steps/sec (HGCN encode + DDPM step)",
         "value": rows_total / elapsed, "unit": "node-steps/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None,
+        "dtype": "f32" if ops.GEMM_MODE == "exact" else
+                 "f32 (GEMM operands carried as 3 bf16 limbs each, 6 exact limb products per fp32 product, fp32 accumulation)",
+        "data": "synthetic",
         "config": {"workload": "configs[1]: SynEgo1000-shaped graph set (1197 ego graphs, sum N=%d, nnz=%d), "
                                "Hyperboloid c=1 HGCN encode (21->%d->%d) + direction-diffusion p_sample "
                                "(mlp denoiser, T=%d tables)" % (w["n"], w["nnz"], a.dim, a.dim, T),
-                   "rows_per_gpu": w["n"], "dim": a.dim, "timesteps": T, "parallelism": "graph-set shards x%d" % world},
-        "roofline": {"bound": "mfma", "kernel": "gemm_f32_mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+                   "rows_per_gpu": w["n"], "dim": a.dim, "timesteps": T, "parallelism": "graph-set shards x%d" % world,
+                   "gemm_mode": ops.GEMM_MODE},
+        "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
+                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                      "traffic_unit": "HBM bytes per launch (mean)", "traffic_source": traffic_src,
-                     "algorithmic_bytes_per_launch": alg_bytes, "launches": len(events),
-                     "gemm_ms_per_step": gemm_ms / a.steps,
+                     "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 6 bf16 MFMA flops per algorithmic fp32 flop; "
+                                   "the exact-f32 MFMA peak is 157.3" if dom != "gemm_f32_mfma" else
+                                   "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+                     "achieved_over_f32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS,
+                     "algorithmic_bytes_per_launch": d["bytes"] / max(1, d["launches"]), "launches": d["launches"],
+                     "kernel_ms_per_step": d["ms"] / a.steps, "all_gemm_ms_per_step": gemm_ms / a.steps,
+                     "other_gemm_kernels": {k: {"launches": v["launches"], "TFLOP/s": v["flops"] / (v["ms"] * 1e-3) / 1e12,
+                                                "ms_per_step": v["ms"] / a.steps}
+                                            for k, v in per.items() if k != dom},
                      "memory_bound_kernels": "profiles/r01_kernel_roofline.jsonl (tools/bench_kernels.py)"},
     }
     enc_ms = sum(e[0].elapsed_time(e[1]) for e in phase) / max(1, len(phase))
@@ -224,6 +263,20 @@ def main():
                         "p_sample_ms": dif_ms,
                         "ddpm_node_steps_per_s_per_gpu": w["n"] / (dif_ms * 1e-3) if dif_ms else None,
                         "note": "HIP-event time of the two phases of one step on rank 0 (SURVEY.md 8d)"}
+    if ops.GEMM_MODE != "exact" and not a.no_exact_leg:
+        # the same K steps on the exact-f32 MFMA kernel (v_mfma_f32_32x32x2_f32), for comparison
+        mode, ops.GEMM_MODE = ops.GEMM_MODE, "exact"
+        try:
+            el2, ev2, _ = timed_steps(w, T, a.steps, min(a.warmup, 3), barrier, ops, dist, device)
+            p2 = gemm_summary(ev2)["gemm_f32_mfma"]
+            ach2 = p2["flops"] / (p2["ms"] * 1e-3) / 1e12
+            out["exact_f32_mfma"] = {"value": rows_total / el2, "unit": "node-steps/s", "ms_per_step": el2 / a.steps * 1e3,
+                                     "roofline": {"bound": "mfma", "kernel": "gemm_f32_mfma", "achieved": ach2,
+                                                  "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                  "frac": ach2 / MFMA_F32_PEAK_TFLOPS},
+                                     "note": "same workload and steps with HD_GEMM_MODE=exact"}
+        finally:
+            ops.GEMM_MODE = mode
     if a.train_steps > 0:
         try:
             out["train"] = train_leg(w, a.dim, device, a.train_steps, 3, barrier, dist)

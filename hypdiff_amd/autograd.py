@@ -43,7 +43,8 @@ def gemm_ex(a, w, bias, resid, aux, c, c2, epi):
               M, N, a.shape[1], a.stride(0), w.stride(0), ref.stride(0), epi, ops._stream())
     if ev is not None:
         e1.record()
-        ev.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)))
+        ev.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N),
+                   "gemm_f32_bf16x3" if ops.GEMM_MODE == "bf16x3" else "gemm_f32_mfma"))
 
 
 def gemm_tn(a, b, out=None):

@@ -197,7 +197,8 @@ def gemm(a, w, bias=None, epi=0, resid=None, out=None):
               w.stride(0), out.stride(0), epi, _stream())
     if ev is not None:
         e1.record()
-        ev.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)))
+        ev.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N),
+                   "gemm_f32_bf16x3" if GEMM_MODE == "bf16x3" else "gemm_f32_mfma"))
     return out
 
 
@@ -267,7 +268,9 @@ def gemm_limbs(a, w, bias=None, epi=0, resid=None, want_f32=True, want_limbs=Fal
               M, N, K, ldc, epi, _stream())
     if ev is not None:
         e1.record()
-        ev.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)))
+        kp, npad = (K + 31) // 32 * 32, (N + 31) // 32 * 32          # limb images: 6 bytes per element
+        ev.append((e0, e1, 2.0 * M * N * K, 6.0 * (M * kp + N * kp) + (4.0 * M * N if c is not None else 0.0)
+                   + (6.0 * M * npad if cl is not None else 0.0), "gemm_limbs"))
     return c, cl
 
 
