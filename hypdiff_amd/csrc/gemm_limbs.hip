@@ -131,7 +131,47 @@ __global__ __launch_bounds__(256) void limb_unpack(const uint4* __restrict__ in,
 
 // epi: 0 none, 1 gelu, 2 resid + gelu (ddpm.py:20-22).  C (fp32 row-major, ldc) and CL (limb image
 // with nslab_out = ceil(N/32) slabs) are both optional outputs of the same values.
-template <int BNT, int WAVES>
+// write-out of 4 consecutive columns nb..nb+3 of row m (tile-local row mloc): bias, epilogue, fp32 and limb stores
+__device__ __forceinline__ void store_quad(float v[4], int m, int mloc, int nb, int half, int N, int nout, int ldc,
+                                           int epi, const float* __restrict__ bias, const float* __restrict__ resid,
+                                           float* __restrict__ C, uint4* __restrict__ CL, size_t cl_tile_base) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int n = nb + e;
+        float x = 0.f;
+        if (n < N) {
+            x = v[e] + (bias ? bias[n] : 0.f);
+            if (epi == 1) x = gelu_erf(x);
+            else if (epi == 2) x = resid[(size_t)m * ldc + n] + gelu_erf(x);
+        }
+        v[e] = x;
+    }
+    if (C) {
+        float* o = C + (size_t)m * ldc + nb;
+        if (nb + 3 < N && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (nb + e < N) o[e] = v[e];
+        }
+    }
+    if (CL && nb < nout) {
+        uint2 h, mm, l;
+        split4(make_float4(v[0], v[1], v[2], v[3]), h, mm, l);
+        const int so = nb >> 5, kc = (nb & 31) >> 3;
+        uint2* o = reinterpret_cast<uint2*>(CL + cl_tile_base + (size_t)so * kTile + kc * 128 + mloc) + half;
+        o[0] = h;
+        o[2 * 4 * 128] = mm;
+        o[2 * 8 * 128] = l;
+    }
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// S16: use v_mfma_f32_16x16x32_bf16 (one k-step per slab, 16x16 tiles) instead of 32x32x16: same
+// MFMA cycles and LDS reads, but the chip holds a higher clock on this shape under load.
+template <int BNT, int WAVES, bool S16>
 __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict__ Ag, const uint4* __restrict__ Wg,
                                                   const float* __restrict__ bias, const float* __restrict__ resid,
                                                   float* __restrict__ C, uint4* __restrict__ CL, int M, int N,
@@ -172,116 +212,149 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
             glds16(ws + piece * (BNT == 128 ? 64 : 128), la + CH_A + piece * 64);           \
         }                                                                                   \
     }
-    // one slab = two k-steps of 16.  Operand maps of v_mfma_f32_32x32x16_bf16: lane (fi = lane&31,
-    // fh = lane>>5) supplies row fi, k = 8 fh .. 8 fh + 7 of the step = chunk kc = 2 s + fh.
-    // First operand = W rows (n), second = A rows (m): the accumulator is the C^T tile.
-    f32x16 acc[2][NT];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int fi = lane & 31, fh = lane >> 5;
-    const int a_off = fh * 128 + wr * 64 + fi, w_off = CH_A + fh * BNT + wc * WCOLS + fi;
+    // LDS-DMA completion is tracked with a counted vmcnt (the group of the next slab stays in
+    // flight) and raw barriers: __syncthreads would drain vmcnt to 0 (an LDS-DMA is a pending
+    // LDS write to the compiler's fence).
+#define HD_WAIT_SLAB(t)                                                                     \
+    if ((t) + 1 < nslab) {                                                                  \
+        static_assert(QA + QW == 12 || QA + QW == 9 || QA + QW == 6, "vmcnt literal below"); \
+        if constexpr (QA + QW == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      \
+        else if constexpr (QA + QW == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   \
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                               \
+    } else {                                                                                \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    \
+    }                                                                                       \
+    __builtin_amdgcn_s_barrier();
+    const int nout = nslab_out * 32;                      // limb image width: zeros from N up to here
+    const size_t cl_base = (size_t)tm * nslab_out * kTile;
 
     // Pipeline: a slab's fragments are pulled into registers in one go, so its LDS buffer is free
-    // again before the multiply starts and the slab two ahead streams into it meanwhile:
-    // two buffers, loads in flight for two slab times.  LDS-DMA completion is tracked with a
-    // counted vmcnt (the group of the next slab stays in flight) and raw barriers: __syncthreads
-    // would drain vmcnt to 0 (an LDS-DMA is a pending LDS write to the compiler's fence).
-    HD_STAGE(0, 0)
-    if (nslab > 1) HD_STAGE(1, 1)
-    for (int t = 0; t < nslab; ++t) {
-        if (t + 1 < nslab) {
-            static_assert(QA + QW == 12 || QA + QW == 9 || QA + QW == 6, "vmcnt literal below");
-            if constexpr (QA + QW == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else if constexpr (QA + QW == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();                       // slab t has landed, for every wave
-        bf16x8 fa[2][2][3], fw[2][NT][3];
-        const uint4* la = &lds[(t & 1) * CH_BUF];
+    // again before the multiply starts and the slab two ahead streams into it meanwhile: two
+    // buffers, loads in flight for two slab times.  First MFMA operand = W rows (n), second = A
+    // rows (m): the accumulator is the C^T tile, a lane owns one m and 4 consecutive n per quad.
+    if constexpr (!S16) {
+        // v_mfma_f32_32x32x16_bf16: lane (fi = lane&31, fh = lane>>5) supplies row fi, k = 8 fh ..
+        // 8 fh + 7 of a k-step of 16 = chunk kc = 2 s + fh; one slab = two k-steps.
+        f32x16 acc[2][NT];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int fi = lane & 31, fh = lane >> 5;
+        const int a_off = fh * 128 + wr * 64 + fi, w_off = CH_A + fh * BNT + wc * WCOLS + fi;
+        HD_STAGE(0, 0)
+        if (nslab > 1) HD_STAGE(1, 1)
+        for (int t = 0; t < nslab; ++t) {
+            HD_WAIT_SLAB(t)                                     // slab t has landed, for every wave
+            bf16x8 fa[2][2][3], fw[2][NT][3];
+            const uint4* la = &lds[(t & 1) * CH_BUF];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int l = 0; l < 3; ++l) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        fa[s][i][l] = __builtin_bit_cast(bf16x8, la[a_off + (l * 4 + 2 * s) * 128 + i * 32]);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        fw[s][j][l] = __builtin_bit_cast(bf16x8, la[w_off + (l * 4 + 2 * s) * BNT + j * 32]);
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                       // every wave holds its fragments: buffer free
+            if (t + 2 < nslab) HD_STAGE(t + 2, t & 1)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        f32x16 c = acc[i][j];
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s][j][0], fa[s][i][2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s][j][2], fa[s][i][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s][j][1], fa[s][i][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s][j][0], fa[s][i][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s][j][1], fa[s][i][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s][j][0], fa[s][i][0], c, 0, 0, 0);
+                        acc[i][j] = c;
+                    }
+        }
+        // C^T tile: lane column = m (fi), registers = n: n = (r&3) + 8*(r>>2) + 4*fh
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mloc = wr * 64 + i * 32 + fi;
+            if (m0 + mloc >= M) continue;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nb = n0 + wc * WCOLS + j * 32 + 8 * g + 4 * fh;
+                    if (nb >= nout && nb >= N) continue;
+                    float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    store_quad(v, m0 + mloc, mloc, nb, fh, N, nout, ldc, epi, bias, resid, C, CL, cl_base);
+                }
+        }
+    } else {
+        // v_mfma_f32_16x16x32_bf16: lane (r16 = lane&15, kq = lane>>4) supplies row r16, k = 8 kq ..
+        // 8 kq + 7 of the 32-deep slab = chunk kc = kq; D: column = lane&15, rows 4 kq + reg.
+        constexpr int MT = 4, NT16 = WCOLS / 16;
+        f32x4 acc[MT][NT16];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT16; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+        const int r16 = lane & 15, kq = lane >> 4;
+        const int a_off = kq * 128 + wr * 64 + r16, w_off = CH_A + kq * BNT + wc * WCOLS + r16;
+        HD_STAGE(0, 0)
+        if (nslab > 1) HD_STAGE(1, 1)
+        for (int t = 0; t < nslab; ++t) {
+            HD_WAIT_SLAB(t)
+            bf16x8 fa[MT][3], fw[NT16][3];
+            const uint4* la = &lds[(t & 1) * CH_BUF];
 #pragma unroll
             for (int l = 0; l < 3; ++l) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    fa[s][i][l] = __builtin_bit_cast(bf16x8, la[a_off + (l * 4 + 2 * s) * 128 + i * 32]);
+                for (int i = 0; i < MT; ++i)
+                    fa[i][l] = __builtin_bit_cast(bf16x8, la[a_off + l * 4 * 128 + i * 16]);
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    fw[s][j][l] = __builtin_bit_cast(bf16x8, la[w_off + (l * 4 + 2 * s) * BNT + j * 32]);
+                for (int j = 0; j < NT16; ++j)
+                    fw[j][l] = __builtin_bit_cast(bf16x8, la[w_off + l * 4 * BNT + j * 16]);
             }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                       // every wave holds its fragments: buffer free
-        if (t + 2 < nslab) HD_STAGE(t + 2, t & 1)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + 2 < nslab) HD_STAGE(t + 2, t & 1)
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s][j][0], fa[s][i][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s][j][2], fa[s][i][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s][j][1], fa[s][i][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s][j][0], fa[s][i][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s][j][1], fa[s][i][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s][j][0], fa[s][i][0], c, 0, 0, 0);
+                for (int j = 0; j < NT16; ++j) {
+                    f32x4 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j][0], fa[i][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j][2], fa[i][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j][1], fa[i][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j][0], fa[i][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j][1], fa[i][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j][0], fa[i][0], c, 0, 0, 0);
                     acc[i][j] = c;
                 }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int mloc = wr * 64 + i * 16 + r16;
+            if (m0 + mloc >= M) continue;
+#pragma unroll
+            for (int j = 0; j < NT16; ++j) {
+                const int nb = n0 + wc * WCOLS + j * 16 + 4 * kq;
+                if (nb >= nout && nb >= N) continue;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                store_quad(v, m0 + mloc, mloc, nb, kq & 1, N, nout, ldc, epi, bias, resid, C, CL, cl_base);
+            }
+        }
     }
 #undef HD_STAGE
-
-    // C^T tile: lane column = m (fi), registers = n: n = (r&3) + 8*(r>>2) + 4*fh
-    const int nout = nslab_out * 32;                      // limb image width: zeros from N up to here
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int mloc = wr * 64 + i * 32 + fi;
-        const int m = m0 + mloc;
-        if (m >= M) continue;
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nb = n0 + wc * WCOLS + j * 32 + 8 * g + 4 * fh;    // 4 consecutive columns
-                if (nb >= nout && nb >= N) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int n = nb + e;
-                    float x = 0.f;
-                    if (n < N) {
-                        x = acc[i][j][4 * g + e] + (bias ? bias[n] : 0.f);
-                        if (epi == 1) x = gelu_erf(x);
-                        else if (epi == 2) x = resid[(size_t)m * ldc + n] + gelu_erf(x);
-                    }
-                    v[e] = x;
-                }
-                if (C) {
-                    float* o = C + (size_t)m * ldc + nb;
-                    if (nb + 3 < N && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
-                        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (nb + e < N) o[e] = v[e];
-                    }
-                }
-                if (CL && nb < nout) {
-                    uint2 h, mm, l;
-                    split4(make_float4(v[0], v[1], v[2], v[3]), h, mm, l);
-                    const int so = nb >> 5, kc = (nb & 31) >> 3;
-                    uint2* o = reinterpret_cast<uint2*>(CL + ((size_t)tm * nslab_out + so) * kTile + kc * 128 + mloc) + fh;
-                    o[0] = h;
-                    o[2 * 4 * 128] = mm;
-                    o[2 * 8 * 128] = l;
-                }
-            }
-    }
+#undef HD_WAIT_SLAB
 }
 
 }  // namespace
@@ -328,19 +401,23 @@ extern "C" int hd_gemm_limbs_f32(const void* A, const void* W, const void* bias,
     const int tiles_m = (int)((M + 127) / 128);
     const int nslab = (int)((K + 31) / 32), nslab_out = (int)((N + 31) / 32);
     // tile: 'n' = 128x64 / 4 wavefronts (two workgroups per CU), 'w' = 128x128 / 4 wavefronts,
-    // 'x' = 128x128 / 8 wavefronts (one workgroup per CU, two wavefronts per SIMD)
-    char cfg = 'n';
+    // 'x' = 128x128 / 8 wavefronts (one workgroup per CU, two wavefronts per SIMD); upper case =
+    // the same on v_mfma_f32_16x16x32_bf16
+    char cfg = 'N';
     if (const char* e = getenv("HD_GEMM_LIMBS_TUNE")) cfg = e[0];
-#define HD_LAUNCH(BNT_, WAVES_)                                                                            \
+#define HD_LAUNCH(BNT_, WAVES_, S16_)                                                                           \
     {                                                                                                      \
         const int tiles_n = (int)((N + BNT_ - 1) / BNT_);                                                  \
-        gemm_limbs<BNT_, WAVES_><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(WAVES_ * 64), 0, (hipStream_t)st>>>( \
+        gemm_limbs<BNT_, WAVES_, S16_><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(WAVES_ * 64), 0, (hipStream_t)st>>>( \
             (const uint4*)A, (const uint4*)W, (const float*)bias, (const float*)resid, (float*)C, (uint4*)CL,  \
             (int)M, (int)N, nslab, (int)ldc, epi, tiles_m, tiles_n, nslab_out);                            \
     }
-    if (cfg == 'n') HD_LAUNCH(64, 4)
-    else if (cfg == 'w') HD_LAUNCH(128, 4)
-    else HD_LAUNCH(128, 8)
+    if (cfg == 'n') HD_LAUNCH(64, 4, false)
+    else if (cfg == 'w') HD_LAUNCH(128, 4, false)
+    else if (cfg == 'x') HD_LAUNCH(128, 8, false)
+    else if (cfg == 'N') HD_LAUNCH(64, 4, true)
+    else if (cfg == 'W') HD_LAUNCH(128, 4, true)
+    else HD_LAUNCH(128, 8, true)
 #undef HD_LAUNCH
     return check_launch("hd_gemm_limbs_f32");
 }
