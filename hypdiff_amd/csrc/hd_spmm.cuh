@@ -27,7 +27,14 @@ namespace hd {
 
 constexpr int kStage = 2048;     // CSR entries staged per block iteration (16 KiB of LDS)
 constexpr int kLongRow = 512;    // rows with more neighbours go to spmm_long
-constexpr int kDepth = 8;        // neighbour rows in flight per lane
+constexpr int kDepth = 8;        // neighbour rows in flight per lane, at most
+// ... such that a lane keeps 128 bytes of gathered rows in flight: wider register tiles take fewer
+// rows (8 x 4 regs, 4 x 8 regs, 2 x 16 regs), which keeps the kernel at 3-4 wavefronts per SIMD
+template <typename T, int REGS>
+constexpr int depth_for() {
+    constexpr int d = 128 / (REGS * (int)sizeof(T));
+    return d > kDepth ? kDepth : (d < 2 ? 2 : d);
+}
 
 enum Epi { E_NONE = 0, E_AGG = 1, E_AGG_ACT = 2 };
 
@@ -41,14 +48,14 @@ __device__ __forceinline__ void agg_epilogue(TL& acc, int epi, const Curv& cin, 
 }
 
 // acc += sum over entries [k0, k1) read through (cols, vals) with index offset `off`
-template <typename T, class TL, class CI, class VI>
+template <typename T, int DEPTH, class TL, class CI, class VI>
 __device__ __forceinline__ void gather_accumulate(TL& acc, const T* __restrict__ x, int d, int k0, int k1,
                                                   const CI& cols, const VI& vals) {
-    for (; k0 < k1; k0 += kDepth) {
-        TL t[kDepth];
-        T w[kDepth];
+    for (; k0 < k1; k0 += DEPTH) {
+        TL t[DEPTH];
+        T w[DEPTH];
 #pragma unroll
-        for (int u = 0; u < kDepth; ++u) {
+        for (int u = 0; u < DEPTH; ++u) {
             t[u].init(d);
             if (k0 + u < k1) {
                 t[u].load(x + (int64_t)cols(k0 + u) * d);
@@ -59,19 +66,20 @@ __device__ __forceinline__ void gather_accumulate(TL& acc, const T* __restrict__
             }
         }
 #pragma unroll
-        for (int u = 0; u < kDepth; ++u)
+        for (int u = 0; u < DEPTH; ++u)
 #pragma unroll
             for (int i = 0; i < TL::kRegs; ++i) acc.v[i] += w[u] * t[u].v[i];
     }
 }
 
 template <class M, typename T, int G, int VEC, int REGS>
-__global__ __launch_bounds__(kBlock) void spmm_rows(const int32_t* __restrict__ rowptr,
+__global__ __launch_bounds__(kBlock, (sizeof(T) == 4 ? 4 : 1)) void spmm_rows(const int32_t* __restrict__ rowptr,
                                                     const int32_t* __restrict__ col,
                                                     const T* __restrict__ val, const T* __restrict__ x,
                                                     T* __restrict__ out, int64_t n, int d, int epi, Curv cin,
                                                     Curv cout, int act, int skip_long) {
     constexpr int RPB = kBlock / G;
+    constexpr int DEPTH = depth_for<T, REGS>();
     __shared__ int32_t s_col[kStage];
     __shared__ T s_val[kStage];
     using TL = Tile<T, G, VEC, REGS>;
@@ -96,11 +104,11 @@ __global__ __launch_bounds__(kBlock) void spmm_rows(const int32_t* __restrict__ 
                 s_val[i] = val[seg0 + i];
             }
             __syncthreads();
-            gather_accumulate<T>(acc, x, d, rs, re, [&](int k) { return s_col[k - seg0]; },
+            gather_accumulate<T, DEPTH>(acc, x, d, rs, re, [&](int k) { return s_col[k - seg0]; },
                                  [&](int k) { return s_val[k - seg0]; });
         } else {
             // a long (unsplit) row in this block: read the lists straight from global memory
-            gather_accumulate<T>(acc, x, d, rs, re, [&](int k) { return col[k]; }, [&](int k) { return val[k]; });
+            gather_accumulate<T, DEPTH>(acc, x, d, rs, re, [&](int k) { return col[k]; }, [&](int k) { return val[k]; });
         }
         if (valid) {
             agg_epilogue<M, T>(acc, epi, cin, cout, act);
@@ -132,7 +140,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void spmm_long(const int32_t* __re
     TL acc;
     acc.init(d);
     acc.zero();
-    gather_accumulate<T>(acc, x, d, k0, k1, [&](int k) { return col[k]; }, [&](int k) { return val[k]; });
+    gather_accumulate<T, depth_for<T, REGS>()>(acc, x, d, k0, k1, [&](int k) { return col[k]; }, [&](int k) { return val[k]; });
     acc.store(part + (size_t)wave * d);
     __syncthreads();
     if (wave == 0) {

@@ -5,6 +5,6 @@ cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_bench_$c
   rm -rf $OUT; mkdir -p $OUT
-  timeout -s KILL 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-exact-leg --train-steps 0 > $OUT/log.txt 2>&1 || exit 1
+  timeout -s KILL 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-exact-leg --no-overlap-leg --train-steps 0 > $OUT/log.txt 2>&1 || exit 1
 done
 python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $GRAFT_REPO_ROOT/gpurun_out/pmc_bench_FETCH_SIZE $GRAFT_REPO_ROOT/gpurun_out/pmc_bench_WRITE_SIZE > $GRAFT_REPO_ROOT/gpurun_out/bench_hbm_traffic.json
