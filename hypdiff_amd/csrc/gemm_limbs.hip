@@ -20,12 +20,12 @@
 // a stored result).  One (rb, s) tile = 1536 chunks = 24 KiB contiguous.
 //
 // Kernel: 256 threads = 2x2 wavefronts over a 128 x BNT tile (BNT = 64: two workgroups per CU),
-// K slabs of 32 double-buffered in LDS: while slab t is multiplied, slab t+1 streams in by
-// global_load_lds (16 B per lane, 1 KiB per wave-instruction, source and destination both
-// linear); one barrier per slab.  Fragment reads are conflict-free by construction (16 lanes =
-// 16 consecutive rows = 256 contiguous bytes).  The MFMA takes W as its first operand and A as
-// its second, so the accumulator holds C^T: a lane owns one row m and 4 consecutive columns per
-// register quad -> 16-byte fp32 stores and 8-byte limb stores (a lane pair completes a chunk).
+// persistent over tiles, K slabs of 32 in two LDS buffers filled by global_load_lds (16 B per
+// lane, 1 KiB per wave-instruction, source and destination both linear) two slabs ahead of the
+// multiply.  Fragment reads are conflict-free by construction (16 lanes = 16 consecutive rows =
+// 256 contiguous bytes).  The MFMA takes W as its first operand and A as its second, so the
+// accumulator holds C^T: a lane owns one row m and 4 consecutive columns per accumulator ->
+// 16-byte fp32 stores and 8-byte limb stores (a lane pair completes a chunk).
 // Replaces x @ W^T of manifolds/poincare.py:96, manifolds/hyperboloid.py:122 and nn.Linear +
 // F.gelu of models/direction_diffusion.py:56-69, ddpm.py:9-41.
 #include "hd_common.cuh"
@@ -169,9 +169,11 @@ __device__ __forceinline__ void store_quad(float v[4], int m, int mloc, int nb, 
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// S16: use v_mfma_f32_16x16x32_bf16 (one k-step per slab, 16x16 tiles) instead of 32x32x16: same
-// MFMA cycles and LDS reads, but the chip holds a higher clock on this shape under load.
-template <int BNT, int WAVES, bool S16>
+// Persistent kernel: workgroup w takes tiles w, w + grid, w + 2 grid, ...; the first slabs of its
+// next tile stream into LDS while the current tile's last slabs are multiplied and written out.
+// v_mfma_f32_16x16x32_bf16 (one k-step per 32-deep slab): same cycles and LDS reads as 32x32x16,
+// but the chip holds a higher clock on this shape under load (measured +13 % on the denoiser chain).
+template <int BNT, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict__ Ag, const uint4* __restrict__ Wg,
                                                   const float* __restrict__ bias, const float* __restrict__ resid,
                                                   float* __restrict__ C, uint4* __restrict__ CL, int M, int N,
@@ -179,29 +181,30 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
                                                   int nslab_out) {
     constexpr int WCN = WAVES / 2;               // wavefronts are laid out 2 (rows) x WCN (columns)
     constexpr int WCOLS = BNT / WCN;             // columns per wavefront: 32 or 64
-    constexpr int NT = WCOLS / 32;               // 32-column MFMA tiles per wavefront along N
+    constexpr int MT = 4, NT16 = WCOLS / 16;     // 16x16 MFMA tiles per wavefront
     constexpr int QA = 24 / WAVES, QW = (12 * BNT / 64) / WAVES;      // 1 KiB pieces per wavefront and slab
     constexpr int CH_A = 12 * 128, CH_W = 12 * BNT, CH_BUF = CH_A + CH_W;
     __shared__ uint4 lds[2 * CH_BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WCN, wc = wave % WCN;
-    // XCD-aware tile order (see gemm.hip): every XCD walks a contiguous run of tiles, N fastest
-    int tile = blockIdx.x;
-    {
-        const int nwg = tiles_m * tiles_n, q = nwg >> 3, r = nwg & 7, xcd = tile & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (tile >> 3);
-    }
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int m0 = tm * 128, n0 = tn * BNT;
-
-    const uint4* a_src = Ag + (size_t)tm * nslab * kTile + lane;
-    const uint4* w_src = Wg + (size_t)(BNT == 128 ? tn : (tn >> 1)) * nslab * kTile + (BNT == 64 ? (tn & 1) * 64 : 0)
-                         + lane;
-    // slab t -> LDS buffer b: 1 KiB pieces, QA (A) + QW (W) per wavefront
-#define HD_STAGE(t, b)                                                                      \
+    const int ntiles = tiles_m * tiles_n;
+    // XCD-aware tile order (see gemm.hip): every XCD walks a contiguous run of tiles, N fastest.
+    // The grid is a multiple of 8 (or covers every tile), so a workgroup's tiles stay on its XCD.
+    auto decode = [&](int v, int& tm_, int& tn_) {
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = v & 7;
+        const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+        tm_ = tile / tiles_n;
+        tn_ = tile - tm_ * tiles_n;
+    };
+    auto a_ptr = [&](int tm_) { return Ag + (size_t)tm_ * nslab * kTile + lane; };
+    auto w_ptr = [&](int tn_) {
+        return Wg + (size_t)(BNT == 128 ? tn_ : (tn_ >> 1)) * nslab * kTile + (BNT == 64 ? (tn_ & 1) * 64 : 0) + lane;
+    };
+    // slab t of the tile with sources (as_, ws_) -> LDS buffer b: 1 KiB pieces, QA (A) + QW (W) per wavefront
+#define HD_STAGE(as_, ws_, t, b)                                                            \
     {                                                                                       \
-        const uint4* as = a_src + (size_t)(t) * kTile;                                      \
-        const uint4* ws = w_src + (size_t)(t) * kTile;                                      \
+        const uint4* as = (as_) + (size_t)(t) * kTile;                                      \
+        const uint4* ws = (ws_) + (size_t)(t) * kTile;                                      \
         uint4* la = &lds[(b) * CH_BUF];                                                     \
         _Pragma("unroll") for (int q = 0; q < QA; ++q) {                                    \
             const int piece = q * WAVES + wave;                                             \
@@ -212,93 +215,31 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
             glds16(ws + piece * (BNT == 128 ? 64 : 128), la + CH_A + piece * 64);           \
         }                                                                                   \
     }
-    // LDS-DMA completion is tracked with a counted vmcnt (the group of the next slab stays in
-    // flight) and raw barriers: __syncthreads would drain vmcnt to 0 (an LDS-DMA is a pending
-    // LDS write to the compiler's fence).
-#define HD_WAIT_SLAB(t)                                                                     \
-    if ((t) + 1 < nslab) {                                                                  \
-        static_assert(QA + QW == 12 || QA + QW == 9 || QA + QW == 6, "vmcnt literal below"); \
-        if constexpr (QA + QW == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      \
-        else if constexpr (QA + QW == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   \
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                               \
-    } else {                                                                                \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    \
-    }                                                                                       \
-    __builtin_amdgcn_s_barrier();
     const int nout = nslab_out * 32;                      // limb image width: zeros from N up to here
-    const size_t cl_base = (size_t)tm * nslab_out * kTile;
+    // operand maps of v_mfma_f32_16x16x32_bf16: lane (r16 = lane&15, kq = lane>>4) supplies row r16,
+    // k = 8 kq .. 8 kq + 7 of the slab = chunk kc = kq.  First operand = W rows (n), second = A rows
+    // (m): the accumulator is the C^T tile, D column = lane&15 = m, D rows 4 kq + reg = n.
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int a_off = kq * 128 + wr * 64 + r16, w_off = CH_A + kq * BNT + wc * WCOLS + r16;
+
+    int vt = blockIdx.x, tm, tn, tm2 = 0, tn2 = 0;
+    decode(vt, tm, tn);
+    // a next tile is prefetched across the tile boundary only when every tile has >= 2 slabs
+    bool has_next = nslab >= 2 && vt + (int)gridDim.x < ntiles;
+    if (has_next) decode(vt + gridDim.x, tm2, tn2);
+    const uint4 *a_cur = a_ptr(tm), *w_cur = w_ptr(tn), *a_nxt = a_ptr(tm2), *w_nxt = w_ptr(tn2);
+    int pb = 0;                                            // slab t of the current tile lives in buffer (pb + t) & 1
 
     // Pipeline: a slab's fragments are pulled into registers in one go, so its LDS buffer is free
-    // again before the multiply starts and the slab two ahead streams into it meanwhile: two
-    // buffers, loads in flight for two slab times.  First MFMA operand = W rows (n), second = A
-    // rows (m): the accumulator is the C^T tile, a lane owns one m and 4 consecutive n per quad.
-    if constexpr (!S16) {
-        // v_mfma_f32_32x32x16_bf16: lane (fi = lane&31, fh = lane>>5) supplies row fi, k = 8 fh ..
-        // 8 fh + 7 of a k-step of 16 = chunk kc = 2 s + fh; one slab = two k-steps.
-        f32x16 acc[2][NT];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        const int fi = lane & 31, fh = lane >> 5;
-        const int a_off = fh * 128 + wr * 64 + fi, w_off = CH_A + fh * BNT + wc * WCOLS + fi;
-        HD_STAGE(0, 0)
-        if (nslab > 1) HD_STAGE(1, 1)
-        for (int t = 0; t < nslab; ++t) {
-            HD_WAIT_SLAB(t)                                     // slab t has landed, for every wave
-            bf16x8 fa[2][2][3], fw[2][NT][3];
-            const uint4* la = &lds[(t & 1) * CH_BUF];
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int l = 0; l < 3; ++l) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        fa[s][i][l] = __builtin_bit_cast(bf16x8, la[a_off + (l * 4 + 2 * s) * 128 + i * 32]);
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        fw[s][j][l] = __builtin_bit_cast(bf16x8, la[w_off + (l * 4 + 2 * s) * BNT + j * 32]);
-                }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                       // every wave holds its fragments: buffer free
-            if (t + 2 < nslab) HD_STAGE(t + 2, t & 1)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        f32x16 c = acc[i][j];
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s][j][0], fa[s][i][2], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s][j][2], fa[s][i][0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s][j][1], fa[s][i][1], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s][j][0], fa[s][i][1], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s][j][1], fa[s][i][0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s][j][0], fa[s][i][0], c, 0, 0, 0);
-                        acc[i][j] = c;
-                    }
-        }
-        // C^T tile: lane column = m (fi), registers = n: n = (r&3) + 8*(r>>2) + 4*fh
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int mloc = wr * 64 + i * 32 + fi;
-            if (m0 + mloc >= M) continue;
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int nb = n0 + wc * WCOLS + j * 32 + 8 * g + 4 * fh;
-                    if (nb >= nout && nb >= N) continue;
-                    float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                    store_quad(v, m0 + mloc, mloc, nb, fh, N, nout, ldc, epi, bias, resid, C, CL, cl_base);
-                }
-        }
-    } else {
-        // v_mfma_f32_16x16x32_bf16: lane (r16 = lane&15, kq = lane>>4) supplies row r16, k = 8 kq ..
-        // 8 kq + 7 of the 32-deep slab = chunk kc = kq; D: column = lane&15, rows 4 kq + reg.
-        constexpr int MT = 4, NT16 = WCOLS / 16;
+    // again before the multiply starts and the slab two ahead (of this tile or the next) streams
+    // into it meanwhile: two buffers, loads in flight for two slab times.  LDS-DMA completion is
+    // tracked with a counted vmcnt -- the youngest group (the slab after the one needed) stays in
+    // flight; stores of a write-out issued in between only make the wait stricter -- and raw
+    // barriers: __syncthreads would drain vmcnt to 0 (an LDS-DMA is a pending LDS write to the
+    // compiler's fence).
+    HD_STAGE(a_cur, w_cur, 0, 0)
+    if (nslab > 1) HD_STAGE(a_cur, w_cur, 1, 1)
+    for (;;) {
         f32x4 acc[MT][NT16];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -306,14 +247,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
             for (int j = 0; j < NT16; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-        const int r16 = lane & 15, kq = lane >> 4;
-        const int a_off = kq * 128 + wr * 64 + r16, w_off = CH_A + kq * BNT + wc * WCOLS + r16;
-        HD_STAGE(0, 0)
-        if (nslab > 1) HD_STAGE(1, 1)
         for (int t = 0; t < nslab; ++t) {
-            HD_WAIT_SLAB(t)
+            if (t + 1 < nslab || has_next) {
+                static_assert(QA + QW == 12 || QA + QW == 9 || QA + QW == 6, "vmcnt literal below");
+                if constexpr (QA + QW == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if constexpr (QA + QW == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();                       // slab t has landed, for every wave
             bf16x8 fa[MT][3], fw[NT16][3];
-            const uint4* la = &lds[(t & 1) * CH_BUF];
+            const uint4* la = &lds[((pb + t) & 1) * CH_BUF];
 #pragma unroll
             for (int l = 0; l < 3; ++l) {
 #pragma unroll
@@ -324,8 +269,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
                     fw[j][l] = __builtin_bit_cast(bf16x8, la[w_off + l * 4 * BNT + j * 16]);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (t + 2 < nslab) HD_STAGE(t + 2, t & 1)
+            __builtin_amdgcn_s_barrier();                       // every wave holds its fragments: buffer free
+            if (t + 2 < nslab) HD_STAGE(a_cur, w_cur, t + 2, (pb + t) & 1)
+            else if (has_next) HD_STAGE(a_nxt, w_nxt, t + 2 - nslab, (pb + t) & 1)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -340,21 +286,34 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
                     acc[i][j] = c;
                 }
         }
+        // write-out of the C^T tile: a lane owns row m and 4 consecutive columns per accumulator
+        {
+            const int m0 = tm * 128, n0 = tn * BNT;
+            const size_t cl_base = (size_t)tm * nslab_out * kTile;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int mloc = wr * 64 + i * 16 + r16;
-            if (m0 + mloc >= M) continue;
+            for (int i = 0; i < MT; ++i) {
+                const int mloc = wr * 64 + i * 16 + r16;
+                if (m0 + mloc >= M) continue;
 #pragma unroll
-            for (int j = 0; j < NT16; ++j) {
-                const int nb = n0 + wc * WCOLS + j * 16 + 4 * kq;
-                if (nb >= nout && nb >= N) continue;
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                store_quad(v, m0 + mloc, mloc, nb, kq & 1, N, nout, ldc, epi, bias, resid, C, CL, cl_base);
+                for (int j = 0; j < NT16; ++j) {
+                    const int nb = n0 + wc * WCOLS + j * 16 + 4 * kq;
+                    if (nb >= nout && nb >= N) continue;
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    store_quad(v, m0 + mloc, mloc, nb, kq & 1, N, nout, ldc, epi, bias, resid, C, CL, cl_base);
+                }
             }
+        }
+        if (!has_next) break;
+        pb = (pb + nslab) & 1;
+        vt += gridDim.x;
+        tm = tm2; tn = tn2; a_cur = a_nxt; w_cur = w_nxt;
+        has_next = vt + (int)gridDim.x < ntiles;
+        if (has_next) {
+            decode(vt + gridDim.x, tm2, tn2);
+            a_nxt = a_ptr(tm2); w_nxt = w_ptr(tn2);
         }
     }
 #undef HD_STAGE
-#undef HD_WAIT_SLAB
 }
 
 }  // namespace
@@ -400,24 +359,36 @@ extern "C" int hd_gemm_limbs_f32(const void* A, const void* W, const void* bias,
     HD_REQUIRE((!C && epi != 2) || ldc >= N, "hd_gemm_limbs_f32: leading dimension too small");
     const int tiles_m = (int)((M + 127) / 128);
     const int nslab = (int)((K + 31) / 32), nslab_out = (int)((N + 31) / 32);
-    // tile: 'n' = 128x64 / 4 wavefronts (two workgroups per CU), 'w' = 128x128 / 4 wavefronts,
-    // 'x' = 128x128 / 8 wavefronts (one workgroup per CU, two wavefronts per SIMD); upper case =
-    // the same on v_mfma_f32_16x16x32_bf16
+    // tile: 'N' = 128x64 / 4 wavefronts (two workgroups per CU), 'W' = 128x128 / 4 wavefronts,
+    // 'X' = 128x128 / 8 wavefronts (one workgroup per CU).  Persistent grid: resident workgroups
+    // only (a multiple of 8, so a workgroup's tiles stay on one XCD), unless K fits one slab.
     char cfg = 'N';
     if (const char* e = getenv("HD_GEMM_LIMBS_TUNE")) cfg = e[0];
-#define HD_LAUNCH(BNT_, WAVES_, S16_)                                                                           \
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    int persist = 1;
+    if (const char* e = getenv("HD_GEMM_LIMBS_PERSIST")) persist = atoi(e);
+#define HD_LAUNCH(BNT_, WAVES_, PER_CU_)                                                                   \
     {                                                                                                      \
         const int tiles_n = (int)((N + BNT_ - 1) / BNT_);                                                  \
-        gemm_limbs<BNT_, WAVES_, S16_><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(WAVES_ * 64), 0, (hipStream_t)st>>>( \
+        const int64_t ntiles = (int64_t)tiles_m * tiles_n;                                                 \
+        HD_REQUIRE(ntiles < (1LL << 31), "hd_gemm_limbs_f32: too many tiles");                             \
+        int64_t grid = ntiles;                                                                             \
+        const int64_t resident = (int64_t)(n_cu * PER_CU_) / 8 * 8;                                        \
+        if (persist && nslab >= 2 && resident >= 8 && grid > resident) grid = resident;                    \
+        gemm_limbs<BNT_, WAVES_><<<dim3((unsigned)grid), dim3(WAVES_ * 64), 0, (hipStream_t)st>>>(         \
             (const uint4*)A, (const uint4*)W, (const float*)bias, (const float*)resid, (float*)C, (uint4*)CL,  \
             (int)M, (int)N, nslab, (int)ldc, epi, tiles_m, tiles_n, nslab_out);                            \
     }
-    if (cfg == 'n') HD_LAUNCH(64, 4, false)
-    else if (cfg == 'w') HD_LAUNCH(128, 4, false)
-    else if (cfg == 'x') HD_LAUNCH(128, 8, false)
-    else if (cfg == 'N') HD_LAUNCH(64, 4, true)
-    else if (cfg == 'W') HD_LAUNCH(128, 4, true)
-    else HD_LAUNCH(128, 8, true)
+    if (cfg == 'W') HD_LAUNCH(128, 4, 1)
+    else if (cfg == 'X') HD_LAUNCH(128, 8, 1)
+    else HD_LAUNCH(64, 4, 2)
 #undef HD_LAUNCH
     return check_launch("hd_gemm_limbs_f32");
 }
