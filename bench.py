@@ -30,9 +30,21 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16 matrix p
 HBM_PEAK_GBS = 8000.0
 # dense MFMA peak per ALGORITHMIC fp32 flop of each GEMM kernel: the limb kernels issue six bf16
 # MFMAs per fp32 product (csrc/gemm_limbs.hip, csrc/gemm_split.hip)
+# MFMAs per fp32 product (csrc/gemm_limbs.hip, csrc/gemm_split.hip); the f16x2 kernel three fp16 MFMAs (same dense rate)
 GEMM_PEAKS = {"gemm_limbs": MFMA_BF16_PEAK_TFLOPS / 6, "gemm_f32_bf16x3": MFMA_BF16_PEAK_TFLOPS / 6,
-              "gemm_f32_mfma": MFMA_F32_PEAK_TFLOPS}
-GEMM_PMC_KEYS = {"gemm_limbs": "gemm_limbs", "gemm_f32_bf16x3": "gemm_f32_bf16x3", "gemm_f32_mfma": "gemm_f32_mfma"}
+              "gemm_f16x2": MFMA_BF16_PEAK_TFLOPS / 3, "gemm_f32_mfma": MFMA_F32_PEAK_TFLOPS}
+# kernel-name prefixes in the rocprofv3 PMC summary (the two limb formats are instantiations of one template)
+GEMM_PMC_KEYS = {"gemm_limbs": "gemm_limbs<64, 4, false", "gemm_f32_bf16x3": "gemm_f32_bf16x3",
+                 "gemm_f16x2": "gemm_limbs<128, 8, true", "gemm_f32_mfma": "gemm_f32_mfma"}
+PEAK_NOTES = {"gemm_limbs": "dense bf16 MFMA peak 2500 TFLOP/s / 6 bf16 MFMAs per algorithmic fp32 product",
+              "gemm_f32_bf16x3": "dense bf16 MFMA peak 2500 TFLOP/s / 6 bf16 MFMAs per algorithmic fp32 product",
+              "gemm_f16x2": "dense fp16 MFMA peak 2500 TFLOP/s / 3 fp16 MFMAs per algorithmic fp32 product",
+              "gemm_f32_mfma": "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"}
+DTYPES = {"exact": "f32",
+          "bf16x3": "f32 (GEMM operands carried as 3 bf16 limbs each, 6 exact limb products per fp32 product, "
+                    "fp32 accumulation)",
+          "f16x2": "f32 (denoiser GEMM operands carried as 2 row-scaled fp16 limbs each, 3 exact limb products per "
+                   "fp32 product, fp32 accumulation, error <= 3*2^-22 |a||w| per product; HypLinear GEMMs as 3 bf16 limbs)"}
 
 
 def gemm_summary(events):
@@ -196,7 +208,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap-leg", action="store_true",
                     help="skip the secondary leg that issues encode and p_sample on two HIP streams")
-    ap.add_argument("--no-exact-leg", action="store_true", help="skip the comparison leg on the exact-f32 MFMA GEMM")
+    ap.add_argument("--no-exact-leg", action="store_true", help="skip the comparison legs on the other fp32 GEMM kernels")
     ap.add_argument("--train-steps", type=int, default=20, help="steps of the secondary training leg (0 = skip)")
     a = ap.parse_args()
 
@@ -250,8 +262,7 @@ def main():
         "value": rows_total / elapsed, "unit": "node-steps/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if ops.GEMM_MODE == "exact" else
-                 "f32 (GEMM operands carried as 3 bf16 limbs each, 6 exact limb products per fp32 product, fp32 accumulation)",
+        "dtype": DTYPES[ops.GEMM_MODE],
         "data": "synthetic",
         "config": {"workload": "configs[1]: SynEgo1000-shaped graph set (1197 ego graphs, sum N=%d, nnz=%d), "
                                "Hyperboloid c=1 HGCN encode (21->%d->%d) + direction-diffusion p_sample "
@@ -261,9 +272,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                      "traffic_unit": "HBM bytes per launch (mean)", "traffic_source": traffic_src,
-                     "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 6 bf16 MFMA flops per algorithmic fp32 flop; "
-                                   "the exact-f32 MFMA peak is 157.3" if dom != "gemm_f32_mfma" else
-                                   "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+                     "peak_note": PEAK_NOTES[dom],
                      "achieved_over_f32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS,
                      "algorithmic_bytes_per_launch": d["bytes"] / max(1, d["launches"]), "launches": d["launches"],
                      "kernel_ms_per_step": d["ms"] / a.steps, "all_gemm_ms_per_step": gemm_ms / a.steps,
@@ -278,18 +287,24 @@ def main():
                         "p_sample_ms": dif_ms,
                         "ddpm_node_steps_per_s_per_gpu": w["n"] / (dif_ms * 1e-3) if dif_ms else None,
                         "note": "HIP-event time of the two phases of one step on rank 0 (SURVEY.md 8d)"}
-    if ops.GEMM_MODE != "exact" and not a.no_exact_leg:
-        # the same K steps on the exact-f32 MFMA kernel (v_mfma_f32_32x32x2_f32), for comparison
-        mode, ops.GEMM_MODE = ops.GEMM_MODE, "exact"
+    if not a.no_exact_leg:
+        # the same K steps under the other fp32 GEMM kernels, for comparison
+        mode = ops.GEMM_MODE
+        out["other_gemm_modes"] = {}
         try:
-            el2, ev2, _ = timed_steps(w, T, a.steps, min(a.warmup, 3), barrier, ops, dist, device)
-            p2 = gemm_summary(ev2)["gemm_f32_mfma"]
-            ach2 = p2["flops"] / (p2["ms"] * 1e-3) / 1e12
-            out["exact_f32_mfma"] = {"value": rows_total / el2, "unit": "node-steps/s", "ms_per_step": el2 / a.steps * 1e3,
-                                     "roofline": {"bound": "mfma", "kernel": "gemm_f32_mfma", "achieved": ach2,
-                                                  "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                                  "frac": ach2 / MFMA_F32_PEAK_TFLOPS},
-                                     "note": "same workload and steps with HD_GEMM_MODE=exact"}
+            for m2 in ("f16x2", "bf16x3", "exact"):
+                if m2 == mode:
+                    continue
+                ops.GEMM_MODE = m2
+                el2, ev2, _ = timed_steps(w, T, a.steps, min(a.warmup, 3), barrier, ops, dist, device)
+                per2 = gemm_summary(ev2)
+                k2 = max(per2, key=lambda k: per2[k]["ms"])
+                ach2 = per2[k2]["flops"] / (per2[k2]["ms"] * 1e-3) / 1e12
+                out["other_gemm_modes"][m2] = {
+                    "value": rows_total / el2, "unit": "node-steps/s", "ms_per_step": el2 / a.steps * 1e3,
+                    "roofline": {"bound": "mfma", "kernel": k2, "achieved": ach2, "peak": GEMM_PEAKS[k2],
+                                 "unit": "TFLOP/s", "frac": ach2 / GEMM_PEAKS[k2]},
+                    "note": "same workload and steps with HD_GEMM_MODE=" + m2}
         finally:
             ops.GEMM_MODE = mode
     if not a.no_overlap_leg:

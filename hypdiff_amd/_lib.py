@@ -5,7 +5,7 @@ shared object is missing, `load()` raises and every op built on it fails loudly.
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhypdiff_hip.so")
@@ -32,6 +32,7 @@ SIZE_QUERIES = {
     "hd_mse_workspace_doubles": [],
     "hd_hkm_workspace_doubles": [I64, I64, I64],
     "hd_limb_image_bytes": [I64, I64],
+    "hd_limb_image_bytes_f16x2": [I64, I64],
 }
 
 # name -> argtypes; names ending in "*" exist as _f32 and _f64
@@ -68,6 +69,9 @@ SIGNATURES = {
     "hd_limb_pack_f32": [P, I64, I64, I64, P, P],
     "hd_limb_unpack_f32": [P, I64, I64, P, I64, P],
     "hd_gemm_limbs_f32": [P, P, P, P, P, P, I64, I64, I64, I64, c_int, P],
+    "hd_limb_pack_f16x2_f32": [P, I64, I64, I64, P, P, P, P],
+    "hd_limb_unpack_f16x2_f32": [P, P, I64, I64, P, I64, P],
+    "hd_gemm_f16x2_f32": [P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, c_int, c_float, c_float, P],
     "hd_gemm_tn_f32": [P, P, P, I64, I64, I64, I64, I64, I64, P, P],
     "hd_transpose_f32": [P, P, I64, I64, I64, I64, P],
     "hd_colsum_f32": [P, P, I64, I64, I64, P, P],

@@ -44,7 +44,7 @@ def gemm_ex(a, w, bias, resid, aux, c, c2, epi):
     if ev is not None:
         e1.record()
         ev.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N),
-                   "gemm_f32_bf16x3" if ops.GEMM_MODE == "bf16x3" else "gemm_f32_mfma"))
+                   "gemm_f32_mfma" if ops.GEMM_MODE == "exact" else "gemm_f32_bf16x3"))
 
 
 def gemm_tn(a, b, out=None):

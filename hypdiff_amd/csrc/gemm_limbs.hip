@@ -26,6 +26,21 @@
 // 256 contiguous bytes).  The MFMA takes W as its first operand and A as its second, so the
 // accumulator holds C^T: a lane owns one row m and 4 consecutive columns per accumulator ->
 // 16-byte fp32 stores and 8-byte limb stores (a lane pair completes a chunk).
+//
+// Second format, "f16x2" (F16 = true): two fp16 limbs per element (22 significant bits) of the row
+// scaled by a power of two, a * 2^e[row] = a_h + a_l, three limb products (hh, hl, lh) per fp32
+// product on v_mfma_f32_16x16x32_f16 -- half the matrix-core work of the bf16 format.  fp16 has
+// 5 exponent bits, so every row carries its own exponent e[row] (removed again, exactly, by
+// v_ldexp_f32 on the accumulator).  For packed inputs and weights e comes from the exact row
+// maximum.  For activations written by a GEMM's epilogue the row maximum of the OUTPUT is not
+// known to a single tile, so e is taken from a bound that is: |c_mn| <= sqrt(K) max|a_m| max_n|w_n|_2
+// + max|b| (Cauchy-Schwarz; max|a_m| is exact -- packed rows carry it, epilogues collect it with
+// an integer atomicMax, deterministic), scaled to [2^13, 2^14).  fp16 keeps an absolute grid of
+// 2^-24 below 2^-14 (subnormals are not flushed by the matrix cores), so a row whose true maximum
+// is 2^-k of the bound is still represented to 2^-(38-k) of its maximum: the bound may be loose
+// by 2^16 before the format loses anything against the 2^-22 of two limbs.  Error model: per
+// product <= 3 * 2^-22 |a||w| worst case (representation 2 * 2^-22, dropped ll 2^-22), absolute
+// 2^-38 * bound per element for rows far below their bound.
 // Replaces x @ W^T of manifolds/poincare.py:96, manifolds/hyperboloid.py:122 and nn.Linear +
 // F.gelu of models/direction_diffusion.py:56-69, ddpm.py:9-41.
 #include "hd_common.cuh"
@@ -37,12 +52,16 @@ using namespace hd;
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kTile = 12 * 128;            // chunks of one (row block, slab) tile
+// limbs per element and chunks of one (row block, slab) tile: 24 KiB (bf16x3) / 16 KiB (f16x2)
+template <bool F16> constexpr int kLimbs = F16 ? 2 : 3;
+template <bool F16> constexpr int kTileOf = 4 * kLimbs<F16> * 128;
 
 __device__ __forceinline__ unsigned pk_bf16(float x, float y) {      // v_cvt_pk_bf16_f32 (RNE)
     const f32x2 v = {x, y};
@@ -50,6 +69,12 @@ __device__ __forceinline__ unsigned pk_bf16(float x, float y) {      // v_cvt_pk
 }
 __device__ __forceinline__ float bf_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
 __device__ __forceinline__ float bf_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+__device__ __forceinline__ unsigned pk_f16(float x, float y) {       // 2 x v_cvt_f16_f32 (RNE)
+    const f32x2 v = {x, y};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+__device__ __forceinline__ float hf_lo(unsigned p) { return (float)__builtin_bit_cast(f16x2, p)[0]; }
+__device__ __forceinline__ float hf_hi(unsigned p) { return (float)__builtin_bit_cast(f16x2, p)[1]; }
 
 // four fp32 -> three limbs of four bf16 (8 bytes each)
 __device__ __forceinline__ void split4(const float4 v, uint2& h, uint2& m, uint2& l) {
@@ -61,16 +86,48 @@ __device__ __forceinline__ void split4(const float4 v, uint2& h, uint2& m, uint2
     l.x = pk_bf16(r0 - bf_lo(m.x), r1 - bf_hi(m.x));
     l.y = pk_bf16(r2 - bf_lo(m.y), r3 - bf_hi(m.y));
 }
+// four (already scaled) fp32 -> two limbs of four fp16; v - h is exact in fp32
+__device__ __forceinline__ void split4_f16(const float4 v, uint2& h, uint2& l) {
+    h.x = pk_f16(v.x, v.y);
+    h.y = pk_f16(v.z, v.w);
+    l.x = pk_f16(v.x - hf_lo(h.x), v.y - hf_hi(h.x));
+    l.y = pk_f16(v.z - hf_lo(h.y), v.w - hf_hi(h.y));
+}
+
+// row exponent e with bound * 2^e in [2^(top-1), 2^top); 0 for a zero / non-finite bound
+__device__ __forceinline__ int exp_for(float bound, int top) {
+    if (!(bound > 0.f) || bound > 3.0e38f) return 0;
+    const int e = top - __builtin_amdgcn_frexp_expf(bound);         // bound < 2^frexp_exp
+    return e < -100 ? -100 : (e > 100 ? 100 : e);
+}
 
 __device__ __forceinline__ void glds16(const uint4* g, uint4* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// exact row maximum of |x| (bit pattern) and the row exponent that scales it to [2^14, 2^15)
+__global__ __launch_bounds__(256) void row_absmax(const float* __restrict__ in, int64_t ld, int rows, int cols,
+                                                  unsigned* __restrict__ amax, int* __restrict__ ex) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* p = in + (int64_t)row * ld;
+    float m = 0.f;
+    for (int c = lane; c < cols; c += 64) m = fmaxf(m, fabsf(p[c]));
+#pragma unroll
+    for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0) {
+        amax[row] = __float_as_uint(m);
+        ex[row] = exp_for(m, 15);
+    }
+}
+
 // fp32 row-major -> limb image.  One thread per (row, 8-column chunk); consecutive threads take
 // consecutive rows, so each limb store of a wavefront is 1 KiB contiguous.
+template <bool F16>
 __global__ __launch_bounds__(256) void limb_pack(const float* __restrict__ in, int64_t ld, int rows, int cols,
-                                                 int nslab, uint4* __restrict__ out, int64_t total) {
+                                                 int nslab, uint4* __restrict__ out, int64_t total,
+                                                 const int* __restrict__ ex) {
     const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;      // ((rb * nslab + s) * 4 + kc) * 128 + r
     if (id >= total) return;
     const int r = (int)(id & 127);
@@ -95,18 +152,31 @@ __global__ __launch_bounds__(256) void limb_pack(const float* __restrict__ in, i
                 if (c0 + e < cols) v[e] = p[e];
         }
     }
-    uint2 h0, m0, l0, h1, m1, l1;
-    split4(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
-    split4(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);
-    uint4* o = out + tile * kTile + kc * 128 + r;
-    o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-    o[4 * 128] = make_uint4(m0.x, m0.y, m1.x, m1.y);
-    o[8 * 128] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    uint4* o = out + tile * kTileOf<F16> + kc * 128 + r;
+    if constexpr (F16) {
+        const int e_row = row < rows ? ex[row] : 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ldexpf(v[e], e_row);
+        uint2 h0, l0, h1, l1;
+        split4_f16(make_float4(v[0], v[1], v[2], v[3]), h0, l0);
+        split4_f16(make_float4(v[4], v[5], v[6], v[7]), h1, l1);
+        o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        o[4 * 128] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    } else {
+        uint2 h0, m0, l0, h1, m1, l1;
+        split4(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
+        split4(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);
+        o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        o[4 * 128] = make_uint4(m0.x, m0.y, m1.x, m1.y);
+        o[8 * 128] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
 }
 
-// limb image -> fp32 row-major (h + m + l in fp32; tests and debugging)
+// limb image -> fp32 row-major (limbs summed in fp32, small first; tests and debugging)
+template <bool F16>
 __global__ __launch_bounds__(256) void limb_unpack(const uint4* __restrict__ in, int rows, int cols, int nslab,
-                                                   float* __restrict__ out, int64_t ld, int64_t total) {
+                                                   float* __restrict__ out, int64_t ld, int64_t total,
+                                                   const int* __restrict__ ex) {
     const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (id >= total) return;
     const int r = (int)(id & 127);
@@ -116,25 +186,54 @@ __global__ __launch_bounds__(256) void limb_unpack(const uint4* __restrict__ in,
     const int s = (int)(tile % nslab);
     const int64_t row = (tile / nslab) * 128 + r;
     if (row >= rows) return;
-    const uint4* p = in + tile * kTile + kc * 128 + r;
-    const uint4 h = p[0], m = p[4 * 128], l = p[8 * 128];
-    const unsigned hh[4] = {h.x, h.y, h.z, h.w}, mm[4] = {m.x, m.y, m.z, m.w}, ll[4] = {l.x, l.y, l.z, l.w};
+    const uint4* p = in + tile * kTileOf<F16> + kc * 128 + r;
     const int c0 = s * 32 + kc * 8;
+    float a[8];
+    if constexpr (F16) {
+        const uint4 h = p[0], l = p[4 * 128];
+        const unsigned hh[4] = {h.x, h.y, h.z, h.w}, ll[4] = {l.x, l.y, l.z, l.w};
+        const int e_row = ex[row];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float a = (bf_lo(ll[e]) + bf_lo(mm[e])) + bf_lo(hh[e]);
-        const float b = (bf_hi(ll[e]) + bf_hi(mm[e])) + bf_hi(hh[e]);
-        if (c0 + 2 * e < cols) out[row * ld + c0 + 2 * e] = a;
-        if (c0 + 2 * e + 1 < cols) out[row * ld + c0 + 2 * e + 1] = b;
+        for (int e = 0; e < 4; ++e) {
+            a[2 * e] = ldexpf(hf_lo(ll[e]) + hf_lo(hh[e]), -e_row);
+            a[2 * e + 1] = ldexpf(hf_hi(ll[e]) + hf_hi(hh[e]), -e_row);
+        }
+    } else {
+        const uint4 h = p[0], m = p[4 * 128], l = p[8 * 128];
+        const unsigned hh[4] = {h.x, h.y, h.z, h.w}, mm[4] = {m.x, m.y, m.z, m.w}, ll[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a[2 * e] = (bf_lo(ll[e]) + bf_lo(mm[e])) + bf_lo(hh[e]);
+            a[2 * e + 1] = (bf_hi(ll[e]) + bf_hi(mm[e])) + bf_hi(hh[e]);
+        }
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        if (c0 + e < cols) out[row * ld + c0 + e] = a[e];
 }
 
-// epi: 0 none, 1 gelu, 2 resid + gelu (ddpm.py:20-22).  C (fp32 row-major, ldc) and CL (limb image
-// with nslab_out = ceil(N/32) slabs) are both optional outputs of the same values.
-// write-out of 4 consecutive columns nb..nb+3 of row m (tile-local row mloc): bias, epilogue, fp32 and limb stores
+// row scales of the f16x2 format (unused by bf16x3): exponents of the A rows (ea) and W rows (ew),
+// exact row maxima of A (amax_a, bit patterns); outputs for the limb image CL: its row exponents
+// (eo) and the running row maxima of the values written (amax_o, atomicMax on bit patterns: zeroed
+// by the caller).  bound on |row of C| = amax_a * bmul + badd.
+struct Scales {
+    const int* ea;
+    const unsigned* amax_a;
+    const int* ew;
+    int* eo;
+    unsigned* amax_o;
+    float bmul, badd;
+};
+
+// epi: 0 none, 1 gelu, 2 resid + gelu (ddpm.py:20-22; bf16x3 only).  C (fp32 row-major, ldc) and CL
+// (limb image with nslab_out = ceil(N/32) slabs) are both optional outputs of the same values.
+// write-out of 4 consecutive columns nb..nb+3 of row m (tile-local row mloc): bias, epilogue, fp32
+// and limb stores; rmax collects max|x| of what was written (f16x2)
+template <bool F16>
 __device__ __forceinline__ void store_quad(float v[4], int m, int mloc, int nb, int half, int N, int nout, int ldc,
                                            int epi, const float* __restrict__ bias, const float* __restrict__ resid,
-                                           float* __restrict__ C, uint4* __restrict__ CL, size_t cl_tile_base) {
+                                           float* __restrict__ C, uint4* __restrict__ CL, size_t cl_tile_base,
+                                           int eo_m, float& rmax) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int n = nb + e;
@@ -143,6 +242,7 @@ __device__ __forceinline__ void store_quad(float v[4], int m, int mloc, int nb, 
             x = v[e] + (bias ? bias[n] : 0.f);
             if (epi == 1) x = gelu_erf(x);
             else if (epi == 2) x = resid[(size_t)m * ldc + n] + gelu_erf(x);
+            if constexpr (F16) rmax = fmaxf(rmax, fabsf(x));
         }
         v[e] = x;
     }
@@ -157,33 +257,49 @@ __device__ __forceinline__ void store_quad(float v[4], int m, int mloc, int nb, 
         }
     }
     if (CL && nb < nout) {
-        uint2 h, mm, l;
-        split4(make_float4(v[0], v[1], v[2], v[3]), h, mm, l);
         const int so = nb >> 5, kc = (nb & 31) >> 3;
-        uint2* o = reinterpret_cast<uint2*>(CL + cl_tile_base + (size_t)so * kTile + kc * 128 + mloc) + half;
-        o[0] = h;
-        o[2 * 4 * 128] = mm;
-        o[2 * 8 * 128] = l;
+        uint2* o = reinterpret_cast<uint2*>(CL + cl_tile_base + (size_t)so * kTileOf<F16> + kc * 128 + mloc) + half;
+        if constexpr (F16) {
+            uint2 h, l;
+            split4_f16(make_float4(ldexpf(v[0], eo_m), ldexpf(v[1], eo_m), ldexpf(v[2], eo_m), ldexpf(v[3], eo_m)), h, l);
+            o[0] = h;
+            o[2 * 4 * 128] = l;
+        } else {
+            uint2 h, mm, l;
+            split4(make_float4(v[0], v[1], v[2], v[3]), h, mm, l);
+            o[0] = h;
+            o[2 * 4 * 128] = mm;
+            o[2 * 8 * 128] = l;
+        }
     }
 }
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N == 4 || N == 6 || N == 8 || N == 9 || N == 12, "add the literal");
+    if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
 
 // Persistent kernel: workgroup w takes tiles w, w + grid, w + 2 grid, ...; the first slabs of its
 // next tile stream into LDS while the current tile's last slabs are multiplied and written out.
-// v_mfma_f32_16x16x32_bf16 (one k-step per 32-deep slab): same cycles and LDS reads as 32x32x16,
-// but the chip holds a higher clock on this shape under load (measured +13 % on the denoiser chain).
-template <int BNT, int WAVES>
+// v_mfma_f32_16x16x32_{bf16,f16} (one k-step per 32-deep slab): same cycles and LDS reads as
+// 32x32x16, but the chip holds a higher clock on this shape under load (measured +13 % on the
+// denoiser chain).
+template <int BNT, int WAVES, bool F16>
 __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict__ Ag, const uint4* __restrict__ Wg,
                                                   const float* __restrict__ bias, const float* __restrict__ resid,
                                                   float* __restrict__ C, uint4* __restrict__ CL, int M, int N,
                                                   int nslab, int ldc, int epi, int tiles_m, int tiles_n,
-                                                  int nslab_out) {
+                                                  int nslab_out, Scales sc) {
+    constexpr int L = kLimbs<F16>, kTile = kTileOf<F16>;
     constexpr int WCN = WAVES / 2;               // wavefronts are laid out 2 (rows) x WCN (columns)
     constexpr int WCOLS = BNT / WCN;             // columns per wavefront: 32 or 64
     constexpr int MT = 4, NT16 = WCOLS / 16;     // 16x16 MFMA tiles per wavefront
-    constexpr int QA = 24 / WAVES, QW = (12 * BNT / 64) / WAVES;      // 1 KiB pieces per wavefront and slab
-    constexpr int CH_A = 12 * 128, CH_W = 12 * BNT, CH_BUF = CH_A + CH_W;
+    constexpr int QA = 8 * L / WAVES, QW = (4 * L * BNT / 64) / WAVES;   // 1 KiB pieces per wavefront and slab
+    constexpr int CH_A = 4 * L * 128, CH_W = 4 * L * BNT, CH_BUF = CH_A + CH_W;
     __shared__ uint4 lds[2 * CH_BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WCN, wc = wave % WCN;
@@ -216,7 +332,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
         }                                                                                   \
     }
     const int nout = nslab_out * 32;                      // limb image width: zeros from N up to here
-    // operand maps of v_mfma_f32_16x16x32_bf16: lane (r16 = lane&15, kq = lane>>4) supplies row r16,
+    // operand maps of v_mfma_f32_16x16x32: lane (r16 = lane&15, kq = lane>>4) supplies row r16,
     // k = 8 kq .. 8 kq + 7 of the slab = chunk kc = kq.  First operand = W rows (n), second = A rows
     // (m): the accumulator is the C^T tile, D column = lane&15 = m, D rows 4 kq + reg = n.
     const int r16 = lane & 15, kq = lane >> 4;
@@ -248,25 +364,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
         for (int t = 0; t < nslab; ++t) {
-            if (t + 1 < nslab || has_next) {
-                static_assert(QA + QW == 12 || QA + QW == 9 || QA + QW == 6, "vmcnt literal below");
-                if constexpr (QA + QW == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                else if constexpr (QA + QW == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            if (t + 1 < nslab || has_next) wait_vmcnt<QA + QW>();
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                       // slab t has landed, for every wave
-            bf16x8 fa[MT][3], fw[NT16][3];
+            uint4 fa[MT][L], fw[NT16][L];
             const uint4* la = &lds[((pb + t) & 1) * CH_BUF];
 #pragma unroll
-            for (int l = 0; l < 3; ++l) {
+            for (int l = 0; l < L; ++l) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    fa[i][l] = __builtin_bit_cast(bf16x8, la[a_off + l * 4 * 128 + i * 16]);
+                for (int i = 0; i < MT; ++i) fa[i][l] = la[a_off + l * 4 * 128 + i * 16];
 #pragma unroll
-                for (int j = 0; j < NT16; ++j)
-                    fw[j][l] = __builtin_bit_cast(bf16x8, la[w_off + l * 4 * BNT + j * 16]);
+                for (int j = 0; j < NT16; ++j) fw[j][l] = la[w_off + l * 4 * BNT + j * 16];
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                       // every wave holds its fragments: buffer free
@@ -277,12 +385,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
 #pragma unroll
                 for (int j = 0; j < NT16; ++j) {
                     f32x4 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j][0], fa[i][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j][2], fa[i][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j][1], fa[i][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j][0], fa[i][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j][1], fa[i][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j][0], fa[i][0], c, 0, 0, 0);
+                    if constexpr (F16) {
+#define HD_MM(wl, al) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fw[j][wl]), \
+                                                                 __builtin_bit_cast(f16x8, fa[i][al]), c, 0, 0, 0);
+                        HD_MM(1, 0) HD_MM(0, 1) HD_MM(0, 0)
+#undef HD_MM
+                    } else {
+#define HD_MM(wl, al) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[j][wl]), \
+                                                                  __builtin_bit_cast(bf16x8, fa[i][al]), c, 0, 0, 0);
+                        HD_MM(0, 2) HD_MM(2, 0) HD_MM(1, 1) HD_MM(0, 1) HD_MM(1, 0) HD_MM(0, 0)
+#undef HD_MM
+                    }
                     acc[i][j] = c;
                 }
         }
@@ -290,16 +403,47 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
         {
             const int m0 = tm * 128, n0 = tn * BNT;
             const size_t cl_base = (size_t)tm * nslab_out * kTile;
+            int ewq[NT16][4];
+            if constexpr (F16) {
+#pragma unroll
+                for (int j = 0; j < NT16; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int n = n0 + wc * WCOLS + j * 16 + 4 * kq + e;
+                        ewq[j][e] = n < N ? sc.ew[n] : 0;
+                    }
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int mloc = wr * 64 + i * 16 + r16;
-                if (m0 + mloc >= M) continue;
+                const int m = m0 + mloc;
+                if (m >= M) continue;
+                int ea_m = 0, eo_m = 0;
+                float rmax = 0.f;
+                if constexpr (F16) {
+                    ea_m = sc.ea[m];
+                    if (CL) {
+                        eo_m = exp_for(__uint_as_float(sc.amax_a[m]) * sc.bmul + sc.badd, 14);
+                        if (tn == 0 && wc == 0 && kq == 0) sc.eo[m] = eo_m;
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < NT16; ++j) {
                     const int nb = n0 + wc * WCOLS + j * 16 + 4 * kq;
                     if (nb >= nout && nb >= N) continue;
                     float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                    store_quad(v, m0 + mloc, mloc, nb, kq & 1, N, nout, ldc, epi, bias, resid, C, CL, cl_base);
+                    if constexpr (F16) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = ldexpf(v[e], -(ea_m + ewq[j][e]));
+                    }
+                    store_quad<F16>(v, m, mloc, nb, kq & 1, N, nout, ldc, epi, bias, resid, C, CL, cl_base, eo_m, rmax);
+                }
+                if constexpr (F16) {
+                    if (sc.amax_o) {                            // the 4 lanes of a row sit 16 apart
+                        rmax = fmaxf(rmax, __shfl_xor(rmax, 16));
+                        rmax = fmaxf(rmax, __shfl_xor(rmax, 32));
+                        if (kq == 0) atomicMax(&sc.amax_o[m], __float_as_uint(rmax));
+                    }
                 }
             }
         }
@@ -316,54 +460,68 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
 #undef HD_STAGE
 }
 
-}  // namespace
-
-extern "C" int64_t hd_limb_image_bytes(int64_t rows, int64_t cols) {
+template <bool F16> int64_t image_bytes(int64_t rows, int64_t cols) {
     if (rows < 0 || cols < 0) return -1;
-    return ((rows + 127) / 128) * ((cols + 31) / 32) * (int64_t)kTile * 16;
+    return ((rows + 127) / 128) * ((cols + 31) / 32) * (int64_t)kTileOf<F16> * 16;
 }
 
-extern "C" int hd_limb_pack_f32(const void* in, int64_t ld, int64_t rows, int64_t cols, void* out, void* st) {
-    HD_REQUIRE(rows >= 0 && cols >= 1 && ld >= cols, "hd_limb_pack_f32: bad shape");
+template <bool F16>
+int pack_impl(const char* who, const void* in, int64_t ld, int64_t rows, int64_t cols, void* out, void* ex,
+              void* amax, void* st) {
+    HD_REQUIRE(rows >= 0 && cols >= 1 && ld >= cols, "%s: bad shape", who);
     if (rows == 0) return HD_OK;
-    HD_REQUIRE(in && out && is_aligned16(out), "hd_limb_pack_f32: null or misaligned pointer");
-    HD_REQUIRE(rows < (1LL << 31) && cols < (1LL << 31), "hd_limb_pack_f32: size exceeds int32");
+    HD_REQUIRE(in && out && is_aligned16(out), "%s: null or misaligned pointer", who);
+    HD_REQUIRE(!F16 || (ex && amax), "%s: null scale arrays", who);
+    HD_REQUIRE(rows < (1LL << 31) && cols < (1LL << 31), "%s: size exceeds int32", who);
     const int nslab = (int)((cols + 31) / 32);
     const int64_t total = ((rows + 127) / 128) * nslab * 4 * 128;
-    limb_pack<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)st>>>(
-        (const float*)in, ld, (int)rows, (int)cols, nslab, (uint4*)out, total);
-    return check_launch("hd_limb_pack_f32");
+    if (F16)
+        row_absmax<<<dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)st>>>(
+            (const float*)in, ld, (int)rows, (int)cols, (unsigned*)amax, (int*)ex);
+    limb_pack<F16><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)st>>>(
+        (const float*)in, ld, (int)rows, (int)cols, nslab, (uint4*)out, total, (const int*)ex);
+    return check_launch(who);
 }
 
-extern "C" int hd_limb_unpack_f32(const void* in, int64_t rows, int64_t cols, void* out, int64_t ld, void* st) {
-    HD_REQUIRE(rows >= 0 && cols >= 1 && ld >= cols, "hd_limb_unpack_f32: bad shape");
+template <bool F16>
+int unpack_impl(const char* who, const void* in, const void* ex, int64_t rows, int64_t cols, void* out, int64_t ld,
+                void* st) {
+    HD_REQUIRE(rows >= 0 && cols >= 1 && ld >= cols, "%s: bad shape", who);
     if (rows == 0) return HD_OK;
-    HD_REQUIRE(in && out, "hd_limb_unpack_f32: null pointer");
+    HD_REQUIRE(in && out && (!F16 || ex), "%s: null pointer", who);
     const int nslab = (int)((cols + 31) / 32);
     const int64_t total = ((rows + 127) / 128) * nslab * 4 * 128;
-    limb_unpack<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)st>>>(
-        (const uint4*)in, (int)rows, (int)cols, nslab, (float*)out, ld, total);
-    return check_launch("hd_limb_unpack_f32");
+    limb_unpack<F16><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)st>>>(
+        (const uint4*)in, (int)rows, (int)cols, nslab, (float*)out, ld, total, (const int*)ex);
+    return check_launch(who);
 }
 
-extern "C" int hd_gemm_limbs_f32(const void* A, const void* W, const void* bias, const void* resid, void* C,
-                                 void* CL, int64_t M, int64_t N, int64_t K, int64_t ldc, int epi, void* st) {
-    HD_REQUIRE(M >= 0 && N >= 1 && K >= 1, "hd_gemm_limbs_f32: bad shape M=%lld N=%lld K=%lld", (long long)M,
-               (long long)N, (long long)K);
+template <bool F16>
+int gemm_impl(const char* who, const void* A, const void* W, const void* bias, const void* resid, void* C, void* CL,
+              int64_t M, int64_t N, int64_t K, int64_t ldc, int epi, Scales sc, void* st) {
+    HD_REQUIRE(M >= 0 && N >= 1 && K >= 1, "%s: bad shape M=%lld N=%lld K=%lld", who, (long long)M, (long long)N,
+               (long long)K);
     if (M == 0) return HD_OK;
-    HD_REQUIRE(A && W && (C || CL), "hd_gemm_limbs_f32: null pointer");
+    HD_REQUIRE(A && W && (C || CL), "%s: null pointer", who);
     HD_REQUIRE(is_aligned16(A) && is_aligned16(W) && (!CL || is_aligned16(CL)),
-               "hd_gemm_limbs_f32: limb images must be 16-byte aligned");
-    HD_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), "hd_gemm_limbs_f32: size exceeds int32");
-    HD_REQUIRE(epi >= 0 && epi <= 2 && (epi != 2 || resid), "hd_gemm_limbs_f32: bad epilogue / missing residual");
-    HD_REQUIRE((!C && epi != 2) || ldc >= N, "hd_gemm_limbs_f32: leading dimension too small");
+               "%s: limb images must be 16-byte aligned", who);
+    HD_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), "%s: size exceeds int32", who);
+    HD_REQUIRE(epi >= 0 && epi <= (F16 ? 1 : 2) && (epi != 2 || resid), "%s: bad epilogue / missing residual", who);
+    HD_REQUIRE((!C && epi != 2) || ldc >= N, "%s: leading dimension too small", who);
+    if (F16) {
+        HD_REQUIRE(sc.ea && sc.ew, "%s: null row exponents", who);
+        HD_REQUIRE(!CL || (sc.amax_a && sc.eo), "%s: a limb-image output needs amax_a and eo", who);
+        if (!CL) sc.amax_o = nullptr;
+    }
     const int tiles_m = (int)((M + 127) / 128);
     const int nslab = (int)((K + 31) / 32), nslab_out = (int)((N + 31) / 32);
-    // tile: 'N' = 128x64 / 4 wavefronts (two workgroups per CU), 'W' = 128x128 / 4 wavefronts,
-    // 'X' = 128x128 / 8 wavefronts (one workgroup per CU).  Persistent grid: resident workgroups
-    // only (a multiple of 8, so a workgroup's tiles stay on one XCD), unless K fits one slab.
-    char cfg = 'N';
-    if (const char* e = getenv("HD_GEMM_LIMBS_TUNE")) cfg = e[0];
+    // tile: 'N' = 128x64 / 4 wavefronts, 'W' = 128x128 / 4 wavefronts, 'X' = 128x128 / 8 wavefronts.
+    // Persistent grid: the workgroups that are resident at once (a multiple of 8, so a
+    // workgroup's tiles stay on one XCD), unless K fits one slab.
+    // Measured on the denoiser shapes (M = 15 777): bf16x3 'N' (two workgroups per CU), f16x2 'X' (two
+    // workgroups = 16 wavefronts per CU; 64 KiB of LDS each).
+    char cfg = F16 ? 'X' : 'N';
+    if (const char* e = getenv(F16 ? "HD_GEMM_F16X2_TUNE" : "HD_GEMM_LIMBS_TUNE")) cfg = e[0];
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -372,23 +530,58 @@ extern "C" int hd_gemm_limbs_f32(const void* A, const void* W, const void* bias,
             n_cu = prop.multiProcessorCount;
         if (n_cu <= 0) n_cu = 256;
     }
-    int persist = 1;
+    int persist = 1, per_cu = 0;
     if (const char* e = getenv("HD_GEMM_LIMBS_PERSIST")) persist = atoi(e);
+    if (const char* e = getenv("HD_GEMM_LIMBS_PER_CU")) per_cu = atoi(e);
 #define HD_LAUNCH(BNT_, WAVES_, PER_CU_)                                                                   \
     {                                                                                                      \
         const int tiles_n = (int)((N + BNT_ - 1) / BNT_);                                                  \
         const int64_t ntiles = (int64_t)tiles_m * tiles_n;                                                 \
-        HD_REQUIRE(ntiles < (1LL << 31), "hd_gemm_limbs_f32: too many tiles");                             \
+        HD_REQUIRE(ntiles < (1LL << 31), "%s: too many tiles", who);                                       \
         int64_t grid = ntiles;                                                                             \
-        const int64_t resident = (int64_t)(n_cu * PER_CU_) / 8 * 8;                                        \
+        const int64_t resident = (int64_t)(n_cu * (per_cu > 0 ? per_cu : PER_CU_)) / 8 * 8;                \
         if (persist && nslab >= 2 && resident >= 8 && grid > resident) grid = resident;                    \
-        gemm_limbs<BNT_, WAVES_><<<dim3((unsigned)grid), dim3(WAVES_ * 64), 0, (hipStream_t)st>>>(         \
+        gemm_limbs<BNT_, WAVES_, F16><<<dim3((unsigned)grid), dim3(WAVES_ * 64), 0, (hipStream_t)st>>>(    \
             (const uint4*)A, (const uint4*)W, (const float*)bias, (const float*)resid, (float*)C, (uint4*)CL,  \
-            (int)M, (int)N, nslab, (int)ldc, epi, tiles_m, tiles_n, nslab_out);                            \
+            (int)M, (int)N, nslab, (int)ldc, epi, tiles_m, tiles_n, nslab_out, sc);                        \
     }
-    if (cfg == 'W') HD_LAUNCH(128, 4, 1)
-    else if (cfg == 'X') HD_LAUNCH(128, 8, 1)
-    else HD_LAUNCH(64, 4, 2)
+    if (cfg == 'W') HD_LAUNCH(128, 4, (F16 ? 2 : 1))
+    else if (cfg == 'X') HD_LAUNCH(128, 8, (F16 ? 2 : 1))
+    else HD_LAUNCH(64, 4, (F16 ? 3 : 2))
 #undef HD_LAUNCH
-    return check_launch("hd_gemm_limbs_f32");
+    return check_launch(who);
+}
+
+}  // namespace
+
+extern "C" int64_t hd_limb_image_bytes(int64_t rows, int64_t cols) { return image_bytes<false>(rows, cols); }
+extern "C" int64_t hd_limb_image_bytes_f16x2(int64_t rows, int64_t cols) { return image_bytes<true>(rows, cols); }
+
+extern "C" int hd_limb_pack_f32(const void* in, int64_t ld, int64_t rows, int64_t cols, void* out, void* st) {
+    return pack_impl<false>("hd_limb_pack_f32", in, ld, rows, cols, out, nullptr, nullptr, st);
+}
+extern "C" int hd_limb_pack_f16x2_f32(const void* in, int64_t ld, int64_t rows, int64_t cols, void* out, void* ex,
+                                      void* amax, void* st) {
+    return pack_impl<true>("hd_limb_pack_f16x2_f32", in, ld, rows, cols, out, ex, amax, st);
+}
+
+extern "C" int hd_limb_unpack_f32(const void* in, int64_t rows, int64_t cols, void* out, int64_t ld, void* st) {
+    return unpack_impl<false>("hd_limb_unpack_f32", in, nullptr, rows, cols, out, ld, st);
+}
+extern "C" int hd_limb_unpack_f16x2_f32(const void* in, const void* ex, int64_t rows, int64_t cols, void* out,
+                                        int64_t ld, void* st) {
+    return unpack_impl<true>("hd_limb_unpack_f16x2_f32", in, ex, rows, cols, out, ld, st);
+}
+
+extern "C" int hd_gemm_limbs_f32(const void* A, const void* W, const void* bias, const void* resid, void* C,
+                                 void* CL, int64_t M, int64_t N, int64_t K, int64_t ldc, int epi, void* st) {
+    return gemm_impl<false>("hd_gemm_limbs_f32", A, W, bias, resid, C, CL, M, N, K, ldc, epi, Scales{}, st);
+}
+extern "C" int hd_gemm_f16x2_f32(const void* A, const void* ea, const void* amax_a, const void* W, const void* ew,
+                                 const void* bias, void* C, void* CL, void* eo, void* amax_o, int64_t M, int64_t N,
+                                 int64_t K, int64_t ldc, int epi, float bound_mul, float bound_add, void* st) {
+    Scales sc{(const int*)ea, (const unsigned*)amax_a, (const int*)ew, (int*)eo, (unsigned*)amax_o, bound_mul,
+              bound_add};
+    HD_REQUIRE(bound_mul >= 0.f && bound_add >= 0.f, "hd_gemm_f16x2_f32: negative bound coefficients");
+    return gemm_impl<true>("hd_gemm_f16x2_f32", A, W, bias, nullptr, C, CL, M, N, K, ldc, epi, sc, st);
 }

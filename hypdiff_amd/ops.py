@@ -18,17 +18,19 @@ ACT_CODES = {"identity": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "elu": 4, "leaky
 
 _curv_cache = {}
 GEMM_EVENTS = None      # set to a list by bench.py to time every hd_gemm_f32 launch
-# fp32 GEMM kernel: "bf16x3" = fp32-accurate 3-limb split on the bf16 matrix cores (6 MFMAs per
-# product term, csrc/gemm_split.hip); "exact" = v_mfma_f32_32x32x2_f32 (csrc/gemm.hip).
-GEMM_MODE = os.environ.get("HD_GEMM_MODE", "bf16x3")
+# fp32 GEMM kernels: "bf16x3" = fp32-accurate 3-limb split on the bf16 matrix cores (6 MFMAs per
+# product term, csrc/gemm_split.hip, csrc/gemm_limbs.hip); "f16x2" = the denoiser chains carry two
+# row-scaled fp16 limbs instead (3 MFMAs per product term, csrc/gemm_limbs.hip), everything else as
+# bf16x3; "exact" = v_mfma_f32_32x32x2_f32 (csrc/gemm.hip).
+GEMM_MODE = os.environ.get("HD_GEMM_MODE", "f16x2")
 
 
 def gemm_symbol():
-    if GEMM_MODE == "bf16x3":
+    if GEMM_MODE in ("bf16x3", "f16x2"):
         return "hd_gemm_f32_bf16x3"
     if GEMM_MODE == "exact":
         return "hd_gemm_f32_ex"
-    raise ValueError("hypdiff_amd.ops.GEMM_MODE must be 'bf16x3' or 'exact', not %r" % (GEMM_MODE,))
+    raise ValueError("hypdiff_amd.ops.GEMM_MODE must be 'bf16x3', 'f16x2' or 'exact', not %r" % (GEMM_MODE,))
 
 
 def curv(c):
@@ -198,65 +200,103 @@ def gemm(a, w, bias=None, epi=0, resid=None, out=None):
     if ev is not None:
         e1.record()
         ev.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N),
-                   "gemm_f32_bf16x3" if GEMM_MODE == "bf16x3" else "gemm_f32_mfma"))
+                   "gemm_f32_mfma" if GEMM_MODE == "exact" else "gemm_f32_bf16x3"))
     return out
 
 
-# ---- limb images: fp32 operands pre-split into 3 bf16 limbs (csrc/gemm_limbs.hip) ------------
+# ---- limb images: fp32 operands pre-split into limbs (csrc/gemm_limbs.hip) ---------------------
 class LimbImage:
-    """A (rows, cols) fp32 matrix stored as its bf16 limb image (include/hypdiff.h)."""
+    """A (rows, cols) fp32 matrix stored as a limb image (include/hypdiff.h): fmt "bf16x3" (three
+    bf16 limbs) or "f16x2" (two fp16 limbs of the row scaled by 2^exp[row]; amax = bit patterns
+    of the exact row maxima of |x|, which bound the rows of the next product)."""
 
-    __slots__ = ("buf", "rows", "cols")
+    __slots__ = ("buf", "rows", "cols", "fmt", "exp", "amax")
 
-    def __init__(self, buf, rows, cols):
-        self.buf, self.rows, self.cols = buf, rows, cols
-
-
-def limb_empty(rows, cols, device):
-    nbytes = _lib.load().hd_limb_image_bytes(rows, cols)
-    return LimbImage(torch.empty(max(nbytes // 4, 4), dtype=torch.int32, device=device), rows, cols)
+    def __init__(self, buf, rows, cols, fmt="bf16x3", exp=None, amax=None):
+        self.buf, self.rows, self.cols, self.fmt, self.exp, self.amax = buf, rows, cols, fmt, exp, amax
 
 
-def limb_pack(x):
+def limb_empty(rows, cols, device, fmt="bf16x3", zero_amax=True):
+    q = "hd_limb_image_bytes" if fmt == "bf16x3" else "hd_limb_image_bytes_f16x2"
+    nbytes = getattr(_lib.load(), q)(rows, cols)
+    buf = torch.empty(max(nbytes // 4, 4), dtype=torch.int32, device=device)
+    if fmt == "bf16x3":
+        return LimbImage(buf, rows, cols)
+    scales = (torch.zeros if zero_amax else torch.empty)(2, max(rows, 1), dtype=torch.int32, device=device)
+    return LimbImage(buf, rows, cols, fmt, scales[0], scales[1])
+
+
+def limb_pack(x, fmt="bf16x3"):
     """fp32 (rows, cols) row-major (any row stride) -> LimbImage."""
     _dev(x)
     assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1
-    img = limb_empty(x.shape[0], x.shape[1], x.device)
-    _lib.call("hd_limb_pack_f32", _p(x), x.stride(0), x.shape[0], x.shape[1], _p(img.buf), _stream())
+    img = limb_empty(x.shape[0], x.shape[1], x.device, fmt, zero_amax=False)
+    if fmt == "bf16x3":
+        _lib.call("hd_limb_pack_f32", _p(x), x.stride(0), x.shape[0], x.shape[1], _p(img.buf), _stream())
+    else:
+        _lib.call("hd_limb_pack_f16x2_f32", _p(x), x.stride(0), x.shape[0], x.shape[1], _p(img.buf), _p(img.exp),
+                  _p(img.amax), _stream())
     return img
 
 
 def limb_unpack(img):
     out = torch.empty(img.rows, img.cols, dtype=torch.float32, device=img.buf.device)
-    _lib.call("hd_limb_unpack_f32", _p(img.buf), img.rows, img.cols, _p(out), out.stride(0), _stream())
+    if img.fmt == "bf16x3":
+        _lib.call("hd_limb_unpack_f32", _p(img.buf), img.rows, img.cols, _p(out), out.stride(0), _stream())
+    else:
+        _lib.call("hd_limb_unpack_f16x2_f32", _p(img.buf), _p(img.exp), img.rows, img.cols, _p(out), out.stride(0),
+                  _stream())
     return out
 
 
 _wlimb_cache = {}
 
 
-def weight_limbs(w):
-    """LimbImage of a weight matrix, rebuilt when the parameter changes (keyed like `curv`)."""
-    hit = _wlimb_cache.get(id(w))
+def weight_limbs(w, fmt="bf16x3"):
+    """(LimbImage, max row 2-norm) of a weight matrix, rebuilt when the parameter changes (keyed
+    like `curv`).  The norm (f16x2 only: one read-back per parameter version) feeds the row bound
+    of the products written as f16x2 images."""
+    key = (id(w), fmt)
+    hit = _wlimb_cache.get(key)
     if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == w.data_ptr():
         return hit[3]
     wd = w.detach()
-    img = limb_pack(wd if wd.stride(1) == 1 else wd.contiguous())
+    img = limb_pack(wd if wd.stride(1) == 1 else wd.contiguous(), fmt)
+    wn = float(wd.double().norm(dim=1).max()) if fmt == "f16x2" else 0.0
     if len(_wlimb_cache) > 256:
         _wlimb_cache.clear()
-    _wlimb_cache[id(w)] = (weakref.ref(w), w._version, w.data_ptr(), img)
-    return img
+    _wlimb_cache[key] = (weakref.ref(w), w._version, w.data_ptr(), (img, wn))
+    return img, wn
 
 
-def gemm_limbs(a, w, bias=None, epi=0, resid=None, want_f32=True, want_limbs=False, out=None):
-    """epi(a @ w.T + bias) from limb images; returns (fp32 tensor or None, LimbImage or None)."""
+_bmax_cache = {}
+
+
+def _bias_absmax(b):
+    if b is None:
+        return 0.0
+    hit = _bmax_cache.get(id(b))
+    if hit is not None and hit[0]() is b and hit[1] == b._version and hit[2] == b.data_ptr():
+        return hit[3]
+    v = float(b.detach().abs().max())
+    if len(_bmax_cache) > 256:
+        _bmax_cache.clear()
+    _bmax_cache[id(b)] = (weakref.ref(b), b._version, b.data_ptr(), v)
+    return v
+
+
+def gemm_limbs(a, w, bias=None, epi=0, resid=None, want_f32=True, want_limbs=False, out=None, w_norm=None,
+               bias_max=None):
+    """epi(a @ w.T + bias) from limb images; returns (fp32 tensor or None, LimbImage or None).
+    f16x2 with want_limbs: w_norm = max row 2-norm of w, bias_max = max|bias| (bounds of the output rows)."""
     M, K, N = a.rows, a.cols, w.rows
-    assert w.cols == K, ((a.rows, a.cols), (w.rows, w.cols))
+    assert w.cols == K and a.fmt == w.fmt, ((a.rows, a.cols, a.fmt), (w.rows, w.cols, w.fmt))
     dev = a.buf.device
+    fmt = a.fmt
     c = None
     if want_f32:
         c = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=dev)
-    cl = limb_empty(M, N, dev) if want_limbs else None
+    cl = limb_empty(M, N, dev, fmt) if want_limbs else None
     ldc = c.stride(0) if c is not None else (resid.stride(0) if resid is not None else N)
     if resid is not None and c is not None:
         assert resid.stride(0) == c.stride(0)
@@ -264,13 +304,28 @@ def gemm_limbs(a, w, bias=None, epi=0, resid=None, want_f32=True, want_limbs=Fal
     if ev is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.call("hd_gemm_limbs_f32", _p(a.buf), _p(w.buf), _p(bias), _p(resid), _p(c), _p(cl.buf) if cl else None,
-              M, N, K, ldc, epi, _stream())
+    if fmt == "bf16x3":
+        _lib.call("hd_gemm_limbs_f32", _p(a.buf), _p(w.buf), _p(bias), _p(resid), _p(c), _p(cl.buf) if cl else None,
+                  M, N, K, ldc, epi, _stream())
+    else:
+        assert resid is None and epi in (0, 1), "f16x2 limb GEMM: epilogues 0 / 1 only"
+        bmul = badd = 0.0
+        if cl is not None:
+            if w_norm is None:
+                w_norm = float(limb_unpack(w).double().norm(dim=1).max())
+            if bias_max is None:
+                bias_max = _bias_absmax(bias)
+            kp = (K + 31) // 32 * 32
+            bmul, badd = kp ** 0.5 * w_norm * (1.0 + 2.0 ** -10), bias_max * (1.0 + 2.0 ** -10)
+        _lib.call("hd_gemm_f16x2_f32", _p(a.buf), _p(a.exp), _p(a.amax), _p(w.buf), _p(w.exp), _p(bias), _p(c),
+                  _p(cl.buf) if cl else None, _p(cl.exp) if cl else None, _p(cl.amax) if cl else None,
+                  M, N, K, ldc, epi, bmul, badd, _stream())
     if ev is not None:
         e1.record()
-        kp, npad = (K + 31) // 32 * 32, (N + 31) // 32 * 32          # limb images: 6 bytes per element
-        ev.append((e0, e1, 2.0 * M * N * K, 6.0 * (M * kp + N * kp) + (4.0 * M * N if c is not None else 0.0)
-                   + (6.0 * M * npad if cl is not None else 0.0), "gemm_limbs"))
+        kp, npad = (K + 31) // 32 * 32, (N + 31) // 32 * 32          # limb images: 6 / 4 bytes per element
+        eb = 6.0 if fmt == "bf16x3" else 4.0
+        ev.append((e0, e1, 2.0 * M * N * K, eb * (M * kp + N * kp) + (4.0 * M * N if c is not None else 0.0)
+                   + (eb * M * npad if cl is not None else 0.0), "gemm_limbs" if fmt == "bf16x3" else "gemm_f16x2"))
     return c, cl
 
 
@@ -278,26 +333,30 @@ def linear_chain(x, layers):
     """Inference-only stack of nn.Linear layers: layers = [(weight, bias, epi), ...] with epi 0
     none, 1 erf-GELU, 2 x + GELU(layer(x)) (ddpm.py:20-22); x fp32 (M, K) on the device.
 
-    GEMM_MODE "bf16x3": activations travel between layers as limb images written by the
+    GEMM_MODE "f16x2" / "bf16x3": activations travel between layers as limb images written by the
     previous GEMM's epilogue (split once per element), weights are split once per parameter
-    version; fp32 copies are written only where a residual or the caller needs them.
+    version; fp32 copies are written only where a residual or the caller needs them.  Chains with
+    a residual epilogue run in the bf16x3 format under either mode.
     GEMM_MODE "exact": one hd_gemm_f32_ex per layer."""
     _dev(x)
-    if GEMM_MODE != "bf16x3":
-        gemm_symbol()
+    if GEMM_MODE == "exact":
         h = x
         for w, b, epi in layers:
             h = gemm(h, w.detach(), None if b is None else b.detach(), epi=epi, resid=h if epi == 2 else None)
         return h
-    a, xf = limb_pack(x), x
+    gemm_symbol()
+    fmt = "f16x2" if GEMM_MODE == "f16x2" and all(epi in (0, 1) for _, _, epi in layers) else "bf16x3"
+    a, xf = limb_pack(x, fmt), x
     for i, (w, b, epi) in enumerate(layers):
         last = i == len(layers) - 1
         need_f32 = last or layers[i + 1][2] == 2
         resid = None
         if epi == 2:
             resid = xf if xf.is_contiguous() else xf.contiguous()
-        xf, a = gemm_limbs(a, weight_limbs(w), None if b is None else b.detach(), epi=epi, resid=resid,
-                           want_f32=need_f32, want_limbs=not last)
+        wl, wn = weight_limbs(w, fmt)
+        bd = None if b is None else b.detach()
+        xf, a = gemm_limbs(a, wl, bd, epi=epi, resid=resid, want_f32=need_f32, want_limbs=not last, w_norm=wn,
+                           bias_max=_bias_absmax(b) if fmt == "f16x2" and not last else None)
     return xf
 
 

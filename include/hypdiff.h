@@ -214,6 +214,26 @@ int hd_limb_pack_f32(const void* in, int64_t ld, int64_t rows, int64_t cols, voi
 int hd_limb_unpack_f32(const void* in, int64_t rows, int64_t cols, void* out, int64_t ld, void* stream);
 int hd_gemm_limbs_f32(const void* A, const void* W, const void* bias, const void* resid, void* C, void* CL,
                       int64_t M, int64_t N, int64_t K, int64_t ldc, int epi, void* stream);
+/* ---- limb images of two row-scaled fp16 limbs ("f16x2"): half the matrix-core work ----
+ * a * 2^ex[row] = a_h + a_l (fp16, 22 significant bits), three limb products (hh, hl, lh) per fp32
+ * product on v_mfma_f32_16x16x32_f16, the row exponents removed exactly from the accumulator.
+ * Image layout as above with 2 limbs: chunk(rb, s, l, kc, r) = (((rb*nslab + s)*2 + l)*4 + kc)*128 + r,
+ * chunks of 8 fp16.  Every image carries ex (int32 per row) and amax (uint32 per row: bit pattern
+ * of the exact max |x| of the row).  hd_limb_pack_f16x2_f32 derives both from the data.
+ * hd_gemm_f16x2_f32: C = epi(A W^T + bias), epi 0 / 1 (erf-GELU), as fp32 (C, ldc) and/or as an
+ * f16x2 image CL with row exponents eo taken from the bound |c_mn| <= amax_a[m] * bound_mul +
+ * bound_add (caller: bound_mul >= sqrt(K) * max_n |w_n|_2, bound_add >= max |bias|) scaled into
+ * [2^13, 2^14), and amax_o = exact row maxima of the values written (integer atomicMax; the
+ * caller zeroes amax_o before the call).  Error: <= 3 * 2^-22 |a||w| per product, plus 2^-38 of
+ * the row bound per stored element.  Same reference lines as hd_gemm_f32. */
+int64_t hd_limb_image_bytes_f16x2(int64_t rows, int64_t cols);
+int hd_limb_pack_f16x2_f32(const void* in, int64_t ld, int64_t rows, int64_t cols, void* out, void* ex, void* amax,
+                           void* stream);
+int hd_limb_unpack_f16x2_f32(const void* in, const void* ex, int64_t rows, int64_t cols, void* out, int64_t ld,
+                             void* stream);
+int hd_gemm_f16x2_f32(const void* A, const void* ea, const void* amax_a, const void* W, const void* ew,
+                      const void* bias, void* C, void* CL, void* eo, void* amax_o, int64_t M, int64_t N, int64_t K,
+                      int64_t ldc, int epi, float bound_mul, float bound_add, void* stream);
 /* Weight gradient dW[P,Q] = A[R,P]^T @ B[R,Q] (A = dL/dz, B = layer input; autograd of
  * F.linear, models/direction_diffusion.py:56-69).  The R rows are split over workgroups and
  * the partial tiles summed in slice order (bit-reproducible).  P, Q, lda, ldb multiples of 4;

@@ -38,7 +38,7 @@ def test_oracle_ddpm_golden(golden):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gemm_mode", ["bf16x3", "exact"])
+@pytest.mark.parametrize("gemm_mode", ["bf16x3", "f16x2", "exact"])
 def test_hip_ddpm_golden(golden, gemm_mode, monkeypatch):
     from hypdiff_amd import ops
     from hypdiff_amd.ddpm import Model

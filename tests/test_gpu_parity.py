@@ -32,14 +32,14 @@ def _lib_loaded():
 
 @pytest.fixture
 def gemm_mode(request):
-    """Run a test under one of the two fp32 GEMM kernels (ops.GEMM_MODE), then restore."""
+    """Run a test under one of the fp32 GEMM kernel families (ops.GEMM_MODE), then restore."""
     from hypdiff_amd import ops
     old, ops.GEMM_MODE = ops.GEMM_MODE, request.param
     yield request.param
     ops.GEMM_MODE = old
 
 
-BOTH_GEMMS = pytest.mark.parametrize("gemm_mode", ["bf16x3", "exact"], indirect=True)
+BOTH_GEMMS = pytest.mark.parametrize("gemm_mode", ["bf16x3", "f16x2", "exact"], indirect=True)
 
 
 # ---------------------------------------------------------------------------------
@@ -366,9 +366,78 @@ def test_limb_images_and_limb_gemm():
         h = z if e == 0 else (torch.nn.functional.gelu(z) if e == 1 else h + torch.nn.functional.gelu(z))
     old = ops.GEMM_MODE
     try:
-        for mode in ("bf16x3", "exact"):
+        for mode in ("bf16x3", "f16x2", "exact"):
             ops.GEMM_MODE = mode
             assert_close(H(ops.linear_chain(x0, layers)), H(h), what="linear_chain " + mode, atol_scale=2e-6)
+    finally:
+        ops.GEMM_MODE = old
+
+
+def test_f16x2_limb_images_and_gemm():
+    """f16x2 limb images (csrc/gemm_limbs.hip): two row-scaled fp16 limbs, three MFMAs per product.
+    Round trip to 2^-22 of the row maximum, integers exact, fp32-accurate contraction over rows
+    spanning 14 orders of magnitude, exact row maxima out of the epilogue, row exponents from the
+    Cauchy-Schwarz bound never overflow fp16, limb write-out equal to the fp32 write-out to 2^-22 of
+    the row maximum, subnormal limbs kept by the matrix cores, and a gelu chain."""
+    from hypdiff_amd import ops
+    rs = np.random.RandomState(6)
+    x = rs.standard_normal((300, 70)).astype(np.float32) * np.exp(rs.standard_normal((300, 1)) * 8).astype(np.float32)
+    x[7] = 0.0
+    x[9, 3] = 1e-30
+    img = ops.limb_pack(G(x), "f16x2")
+    rowmax = np.abs(x).max(axis=1, keepdims=True)
+    assert np.all(np.abs(H(ops.limb_unpack(img)) - x) <= 2.0 ** -22 * rowmax)
+    assert np.array_equal(H(img.amax.view(torch.float32)), rowmax[:, 0])
+    xi = rs.randint(-2000, 2001, size=(130, 40)).astype(np.float32)               # 11-bit integers: one limb
+    assert np.array_equal(H(ops.limb_unpack(ops.limb_pack(G(xi), "f16x2"))), xi)
+    # fp16 subnormals take part in the product (a flushing matrix core would lose all of it)
+    a = np.full((128, 64), 2.0 ** -30, np.float32) * (1 + rs.rand(128, 64).astype(np.float32))
+    a[:, 0] = 1.5
+    w = rs.standard_normal((64, 64)).astype(np.float32)
+    w[:, 0] = 0.0
+    got, _ = ops.gemm_limbs(ops.limb_pack(G(a), "f16x2"), ops.limb_pack(G(w), "f16x2"))
+    ref = a.astype(np.float64) @ w.astype(np.float64).T
+    mag = np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64).T
+    assert np.all(np.abs(H(got) - ref) <= 2.0 ** -8 * mag)
+    for (M, N, K) in [(1, 5, 8), (129, 700, 900), (300, 64, 516), (1000, 800, 65), (257, 130, 36), (128, 64, 32),
+                      (385, 896, 64)]:
+        ai = rs.randint(-4, 5, size=(M, K)).astype(np.float32)
+        wi = rs.randint(-4, 5, size=(N, K)).astype(np.float32)
+        got, _ = ops.gemm_limbs(ops.limb_pack(G(ai), "f16x2"), ops.limb_pack(G(wi), "f16x2"))
+        assert np.array_equal(H(got), ai @ wi.T)
+        a = rs.standard_normal((M, K)).astype(np.float32) * np.exp(rs.standard_normal((M, 1)) * 8).astype(np.float32)
+        w = rs.standard_normal((N, K)).astype(np.float32) * np.exp(rs.standard_normal((N, 1)) * 3).astype(np.float32)
+        b = rs.standard_normal(N).astype(np.float32)
+        ref = a.astype(np.float64) @ w.astype(np.float64).T + b
+        mag = np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64).T + np.abs(b)
+        al, wl = ops.limb_pack(G(a), "f16x2"), ops.limb_pack(G(w), "f16x2")
+        c, cl = ops.gemm_limbs(al, wl, G(b), want_f32=True, want_limbs=True)
+        hc = H(c)
+        assert np.all(np.abs(hc - ref) <= 2e-6 * mag), (M, N, K, (np.abs(hc - ref) / mag).max())
+        cmax = np.abs(hc).max(axis=1)
+        assert np.array_equal(H(cl.amax.view(torch.float32)), cmax)               # exact, order-independent
+        scaled = cmax.astype(np.float64) * 2.0 ** H(cl.exp).astype(np.float64)
+        assert np.all(scaled < 2.0 ** 14), scaled.max()                           # the bound is a bound
+        # two 11-bit limbs; below 2^-14 (scaled) fp16 is a fixed grid of 2^-24
+        grid = 2.0 ** -24 * 2.0 ** -H(cl.exp).astype(np.float64)
+        assert np.all(np.abs(H(ops.limb_unpack(cl)).astype(np.float64) - hc) <= 2.0 ** -22 * np.abs(hc) + grid[:, None])
+        gl, gll = ops.gemm_limbs(al, wl, G(b), epi=1, want_f32=True, want_limbs=True)
+        want = torch.nn.functional.gelu(torch.from_numpy(ref)).numpy()
+        assert np.all(np.abs(H(gl) - want) <= 2e-6 * mag + 1e-30)
+        assert np.array_equal(H(gll.amax.view(torch.float32)), np.abs(H(gl)).max(axis=1))
+    ws = [torch.from_numpy((rs.standard_normal(s) / np.sqrt(s[1])).astype(np.float32)).cuda()
+          for s in [(96, 68), (200, 96), (96, 200), (10, 96)]]
+    bs = [torch.from_numpy(rs.standard_normal(w.shape[0]).astype(np.float32)).cuda() for w in ws]
+    x0 = G(rs.standard_normal((333, 68)).astype(np.float32) * np.exp(rs.standard_normal((333, 1)) * 4).astype(np.float32))
+    layers = [(w, b, e) for w, b, e in zip(ws, bs, (1, 1, 1, 0))]
+    h = x0.double()
+    for w, b, e in layers:
+        z = h @ w.double().T + b.double()
+        h = z if e == 0 else torch.nn.functional.gelu(z)
+    old = ops.GEMM_MODE
+    try:
+        ops.GEMM_MODE = "f16x2"
+        assert_close(H(ops.linear_chain(x0, layers)), H(h), what="linear_chain f16x2 (gelu)", atol_scale=2e-6)
     finally:
         ops.GEMM_MODE = old
 
