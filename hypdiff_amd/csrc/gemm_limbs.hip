@@ -172,6 +172,67 @@ __global__ __launch_bounds__(256) void limb_pack(const float* __restrict__ in, i
     }
 }
 
+// mlp input cat(x.float(), t[:,None]) (models/direction_diffusion.py:57-58) -> f16x2 limb image in one
+// pass over the latents: one wavefront per row, a lane owns the 8-column chunks lane, lane + 64, ...;
+// the row maximum is a wavefront reduction, so the row is read once and no fp32 copy is made.
+constexpr int kPackChunks = 3;                                    // chunks per lane: dim + 1 <= 1536
+template <typename TX>
+__global__ __launch_bounds__(256) void mlp_pack_f16x2(const TX* __restrict__ x, const void* __restrict__ t, int t_kind,
+                                                      float t_scalar, int rows, int dim, int nslab,
+                                                      uint4* __restrict__ out, int* __restrict__ ex,
+                                                      unsigned* __restrict__ amax) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    constexpr int V = 16 / sizeof(TX);
+    using VT = typename VecOf<TX>::type;
+    const TX* xr = x + (int64_t)row * dim;
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(xr) & 15) == 0;
+    const float tv = t_kind == 0 ? (float)((const int64_t*)t)[row] : (t_kind == 1 ? ((const float*)t)[row] : t_scalar);
+    const int nchunk = nslab * 4;
+    float v[kPackChunks][8];
+    float m = 0.f;
+#pragma unroll
+    for (int q = 0; q < kPackChunks; ++q) {
+        const int c0 = (lane + 64 * q) * 8;
+        if (c0 + 8 <= dim && vec_ok) {
+#pragma unroll
+            for (int g = 0; g < 8 / V; ++g) {
+                const VT pk = *reinterpret_cast<const VT*>(xr + c0 + g * V);
+                const TX* pe = reinterpret_cast<const TX*>(&pk);
+#pragma unroll
+                for (int e = 0; e < V; ++e) v[q][g * V + e] = (float)pe[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = c0 + e;
+                v[q][e] = c < dim ? (float)xr[c] : (c == dim ? tv : 0.f);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[q][e]));
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    const int e_row = exp_for(m, 15);
+    if (lane == 0) {
+        amax[row] = __float_as_uint(m);
+        ex[row] = e_row;
+    }
+    uint4* orow = out + (int64_t)(row >> 7) * nslab * kTileOf<true> + (row & 127);
+#pragma unroll
+    for (int q = 0; q < kPackChunks; ++q) {
+        const int ch = lane + 64 * q;
+        if (ch >= nchunk) continue;
+        uint2 h0, l0, h1, l1;
+        split4_f16(make_float4(ldexpf(v[q][0], e_row), ldexpf(v[q][1], e_row), ldexpf(v[q][2], e_row), ldexpf(v[q][3], e_row)), h0, l0);
+        split4_f16(make_float4(ldexpf(v[q][4], e_row), ldexpf(v[q][5], e_row), ldexpf(v[q][6], e_row), ldexpf(v[q][7], e_row)), h1, l1);
+        uint4* o = orow + (int64_t)(ch >> 2) * kTileOf<true> + (ch & 3) * 128;
+        o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        o[4 * 128] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+}
+
 // limb image -> fp32 row-major (limbs summed in fp32, small first; tests and debugging)
 template <bool F16>
 __global__ __launch_bounds__(256) void limb_unpack(const uint4* __restrict__ in, int rows, int cols, int nslab,
@@ -563,6 +624,25 @@ extern "C" int hd_limb_pack_f32(const void* in, int64_t ld, int64_t rows, int64_
 extern "C" int hd_limb_pack_f16x2_f32(const void* in, int64_t ld, int64_t rows, int64_t cols, void* out, void* ex,
                                       void* amax, void* st) {
     return pack_impl<true>("hd_limb_pack_f16x2_f32", in, ld, rows, cols, out, ex, amax, st);
+}
+
+extern "C" int hd_mlp_pack_input_f16x2(const void* x, int x_dtype, const void* t, int t_kind, double t_scalar,
+                                       void* out, void* ex, void* amax, int64_t rows, int64_t dim, void* st) {
+    HD_REQUIRE(rows >= 0 && dim >= 1 && dim + 1 <= 64 * 8 * kPackChunks, "hd_mlp_pack_input_f16x2: dim out of range (<= %d)",
+               64 * 8 * kPackChunks - 1);
+    if (rows == 0) return HD_OK;
+    HD_REQUIRE(x && out && ex && amax && (t || t_kind == 2) && t_kind >= 0 && t_kind <= 2 && is_aligned16(out),
+               "hd_mlp_pack_input_f16x2: bad argument");
+    HD_REQUIRE(rows < (1LL << 31), "hd_mlp_pack_input_f16x2: size exceeds int32");
+    const int nslab = (int)((dim + 1 + 31) / 32);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (x_dtype)
+        mlp_pack_f16x2<double><<<grid, 256, 0, (hipStream_t)st>>>((const double*)x, t, t_kind, (float)t_scalar, (int)rows,
+                                                                  (int)dim, nslab, (uint4*)out, (int*)ex, (unsigned*)amax);
+    else
+        mlp_pack_f16x2<float><<<grid, 256, 0, (hipStream_t)st>>>((const float*)x, t, t_kind, (float)t_scalar, (int)rows,
+                                                                 (int)dim, nslab, (uint4*)out, (int*)ex, (unsigned*)amax);
+    return check_launch("hd_mlp_pack_input_f16x2");
 }
 
 extern "C" int hd_limb_unpack_f32(const void* in, int64_t rows, int64_t cols, void* out, int64_t ld, void* st) {

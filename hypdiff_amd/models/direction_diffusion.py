@@ -151,7 +151,6 @@ class mlp(nn.Module):
         x = x.contiguous()
         n, d = x.shape
         ld = (d + 1 + 3) // 4 * 4
-        h = torch.empty(n, ld, dtype=torch.float32, device=x.device)
         if torch.is_tensor(t):
             if t.dtype == torch.int64:
                 kind, tp, ts = 0, t.contiguous(), 0.0
@@ -160,6 +159,16 @@ class mlp(nn.Module):
                 kind, ts = 1, 0.0
         else:
             kind, tp, ts = 2, None, float(t)
+        chain = [(self.fc1.weight, self.fc1.bias, 1), (self.fc2.weight, self.fc2.bias, 1),
+                 (self.fc3.weight, self.fc3.bias, 1), (self.fc4.weight, self.fc4.bias, 1),
+                 (self.fc5.weight, self.fc5.bias, 0)]
+        if ops.GEMM_MODE == "f16x2" and d + 1 <= 1536 and not hag.wants_grad(*self.parameters()):
+            # inference: the concat goes straight into the limb image of the first GEMM's operand
+            img = ops.limb_empty(n, d + 1, x.device, "f16x2", zero_amax=False)
+            ops._lib.call("hd_mlp_pack_input_f16x2", ops._p(x), 1 if x.dtype == torch.float64 else 0, ops._p(tp), kind,
+                          ts, ops._p(img.buf), ops._p(img.exp), ops._p(img.amax), n, d, ops._stream())
+            return ops.linear_chain(img, chain)
+        h = torch.empty(n, ld, dtype=torch.float32, device=x.device)
         ops._lib.call("hd_mlp_pack_input", ops._p(x), 1 if x.dtype == torch.float64 else 0, ops._p(tp), kind, ts,
                       ops._p(h), n, d, ld, ops._stream())
         if hag.wants_grad(*self.parameters()):
@@ -170,10 +179,7 @@ class mlp(nn.Module):
             h1 = ops.gemm(h, self._w1(ld), self.fc1.bias.detach(), epi=1)
         else:
             h, h1 = h[:, : d + 1], None
-        return ops.linear_chain(h if h1 is None else h1,
-                                ([(self.fc1.weight, self.fc1.bias, 1)] if h1 is None else []) +
-                                [(self.fc2.weight, self.fc2.bias, 1), (self.fc3.weight, self.fc3.bias, 1),
-                                 (self.fc4.weight, self.fc4.bias, 1), (self.fc5.weight, self.fc5.bias, 0)])
+        return ops.linear_chain(h if h1 is None else h1, chain[1:] if h1 is not None else chain)
 
 
 def get_alphas(timesteps):

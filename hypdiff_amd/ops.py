@@ -338,15 +338,20 @@ def linear_chain(x, layers):
     version; fp32 copies are written only where a residual or the caller needs them.  Chains with
     a residual epilogue run in the bf16x3 format under either mode.
     GEMM_MODE "exact": one hd_gemm_f32_ex per layer."""
-    _dev(x)
+    if not isinstance(x, LimbImage):
+        _dev(x)
     if GEMM_MODE == "exact":
         h = x
         for w, b, epi in layers:
             h = gemm(h, w.detach(), None if b is None else b.detach(), epi=epi, resid=h if epi == 2 else None)
         return h
     gemm_symbol()
-    fmt = "f16x2" if GEMM_MODE == "f16x2" and all(epi in (0, 1) for _, _, epi in layers) else "bf16x3"
-    a, xf = limb_pack(x, fmt), x
+    if isinstance(x, LimbImage):                      # operand packed by the caller (mlp input)
+        fmt, a, xf = x.fmt, x, None
+        assert all(epi in (0, 1) for _, _, epi in layers)
+    else:
+        fmt = "f16x2" if GEMM_MODE == "f16x2" and all(epi in (0, 1) for _, _, epi in layers) else "bf16x3"
+        a, xf = limb_pack(x, fmt), x
     for i, (w, b, epi) in enumerate(layers):
         last = i == len(layers) - 1
         need_f32 = last or layers[i + 1][2] == 2

@@ -231,6 +231,11 @@ int hd_limb_pack_f16x2_f32(const void* in, int64_t ld, int64_t rows, int64_t col
                            void* stream);
 int hd_limb_unpack_f16x2_f32(const void* in, const void* ex, int64_t rows, int64_t cols, void* out, int64_t ld,
                              void* stream);
+/* cat(x.float(), t[:,None]) (models/direction_diffusion.py:57-58) written directly as the f16x2 image
+ * of the (rows, dim+1) denoiser input: x f32/f64 (x_dtype 0/1) row-major contiguous, t as in
+ * hd_mlp_pack_input; dim + 1 <= 1536. */
+int hd_mlp_pack_input_f16x2(const void* x, int x_dtype, const void* t, int t_kind, double t_scalar, void* out,
+                            void* ex, void* amax, int64_t rows, int64_t dim, void* stream);
 int hd_gemm_f16x2_f32(const void* A, const void* ea, const void* amax_a, const void* W, const void* ew,
                       const void* bias, void* C, void* CL, void* eo, void* amax_o, int64_t M, int64_t N, int64_t K,
                       int64_t ldc, int epi, float bound_mul, float bound_add, void* stream);

@@ -425,6 +425,24 @@ def test_f16x2_limb_images_and_gemm():
         want = torch.nn.functional.gelu(torch.from_numpy(ref)).numpy()
         assert np.all(np.abs(H(gl) - want) <= 2e-6 * mag + 1e-30)
         assert np.array_equal(H(gll.amax.view(torch.float32)), np.abs(H(gl)).max(axis=1))
+    # fused denoiser-input pack (cat(x, t) -> image) == pack_input followed by limb_pack, bit for bit
+    for d, dt in [(512, np.float64), (511, np.float64), (14, np.float32), (700, np.float32), (1535, np.float64)]:
+        n = 261
+        xx = (rs.standard_normal((n, d)) * np.exp(rs.standard_normal((n, 1)) * 3)).astype(dt)
+        for kind, tv in [(0, torch.from_numpy(rs.randint(0, 1000, size=n)).cuda()),
+                         (1, torch.from_numpy(rs.rand(n).astype(np.float32)).cuda()), (2, 37.0)]:
+            tp, ts = (tv, 0.0) if kind != 2 else (None, tv)
+            ld = (d + 1 + 3) // 4 * 4
+            hbuf = torch.empty(n, ld, dtype=torch.float32, device="cuda")
+            xg = G(xx)
+            ops._lib.call("hd_mlp_pack_input", ops._p(xg), int(dt == np.float64), ops._p(tp), kind, ts, ops._p(hbuf),
+                          n, d, ld, ops._stream())
+            want = ops.limb_pack(hbuf[:, : d + 1], "f16x2")
+            img = ops.limb_empty(n, d + 1, "cuda", "f16x2", zero_amax=False)
+            ops._lib.call("hd_mlp_pack_input_f16x2", ops._p(xg), int(dt == np.float64), ops._p(tp), kind, ts,
+                          ops._p(img.buf), ops._p(img.exp), ops._p(img.amax), n, d, ops._stream())
+            assert torch.equal(img.exp, want.exp) and torch.equal(img.amax, want.amax), (d, dt, kind)
+            assert np.array_equal(H(ops.limb_unpack(img)), H(ops.limb_unpack(want))), (d, dt, kind)
     ws = [torch.from_numpy((rs.standard_normal(s) / np.sqrt(s[1])).astype(np.float32)).cuda()
           for s in [(96, 68), (200, 96), (96, 200), (10, 96)]]
     bs = [torch.from_numpy(rs.standard_normal(w.shape[0]).astype(np.float32)).cuda() for w in ws]
