@@ -73,7 +73,7 @@ class HypLinear(nn.Module):
 
     def _weight(self):
         # weight dropout stays a torch op ahead of the kernel (:99)
-        w = self.weight if torch.is_grad_enabled() else self.weight.detach()
+        w = self.weight         # the parameter object itself: ops caches its padded copy by identity
         if self.training and self.dropout > 0:
             return F.dropout(w, self.dropout, training=True)
         return w

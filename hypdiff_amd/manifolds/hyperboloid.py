@@ -46,6 +46,7 @@ class Hyperboloid(Manifold):
             return hag.HypLinearFn.apply(x2, m, "hb", ops.curv(c), _flags)
         if m.dtype != x2.dtype:
             m = m.to(x2.dtype)
+        m = ops.match_padded(x2, m)
         u = ops.map1("hd_hb_logmap0", x2, c)
         mu = ops.gemm(u, m)
         out = torch.empty_like(mu)

@@ -57,6 +57,7 @@ class PoincareBall(Manifold):
             return hag.HypLinearFn.apply(x2, m, "pb", ops.curv(c), _flags).view(shape[:-1] + (m.shape[0],))
         if m.dtype != x2.dtype:
             m = m.to(x2.dtype)
+        m = ops.match_padded(x2, m)
         xn = ops.rownorm(x2)
         mx = ops.gemm(x2, m)
         out = torch.empty_like(mx)

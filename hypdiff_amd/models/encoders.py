@@ -1,5 +1,6 @@
 """Hyperbolic graph encoders -- drop-in for HNN / HGCN of the reference's
 models/encoders.py:48-71,91-119 (the Euclidean baselines are out of scope)."""
+import torch
 import torch.nn as nn
 
 from .. import manifolds, ops
@@ -22,7 +23,12 @@ class Encoder(nn.Module):
 
 
 def _lift(manifold, x, c):
-    """proj(expmap0(proj_tan0(x))) in one pass (encoders.py:70,116-118)"""
+    """proj(expmap0(proj_tan0(x))) in one pass (encoders.py:70,116-118).  Inference on fp32
+    features whose width is not a multiple of 4: the (persistent) feature matrix is zero-padded to
+    16-byte rows once (cached); zero columns stay zero through the lift and the first layer's
+    weight is padded to match (ops.match_padded), so nothing is padded per call."""
+    if x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] % 4 and not torch.is_grad_enabled():
+        x = ops.pad_k_cached(x, (x.shape[1] + 3) // 4 * 4)
     return ops.map1("hd_%s_expmap0_proj" % manifold.abi, x, c)
 
 

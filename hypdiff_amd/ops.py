@@ -173,6 +173,33 @@ def _pad_k(t, k_pad):
     return out
 
 
+_pad_cache = {}
+
+
+def pad_k_cached(t, k_pad):
+    """_pad_k for operands that persist between calls (weights, input features): the padded copy
+    is rebuilt only when the tensor object, its version counter or its storage changes."""
+    if t.shape[1] == k_pad and t.is_contiguous() and t.data_ptr() % 16 == 0:
+        return t
+    hit = _pad_cache.get(id(t))
+    if hit is not None and hit[0]() is t and hit[1] == (t._version, t.data_ptr(), k_pad):
+        return hit[2]
+    out = _pad_k(t.detach(), k_pad)
+    if len(_pad_cache) > 64:
+        _pad_cache.clear()
+    _pad_cache[id(t)] = (weakref.ref(t), (t._version, t.data_ptr(), k_pad), out)
+    return out
+
+
+def match_padded(x2, m):
+    """A weight whose input carries zero pad columns (models/encoders._lift pads the features to
+    16-byte rows once): pad the weight's K to the same width (cached per parameter version)."""
+    if x2.shape[1] != m.shape[1]:
+        assert x2.shape[1] == (m.shape[1] + 3) // 4 * 4, (x2.shape, m.shape)
+        m = pad_k_cached(m, x2.shape[1])
+    return m
+
+
 def gemm(a, w, bias=None, epi=0, resid=None, out=None):
     """epi(a @ w.T + bias): fp32 on the exact-f32 matrix cores, fp64 on the vector ALU."""
     _dev(a, w, bias)
@@ -188,7 +215,7 @@ def gemm(a, w, bias=None, epi=0, resid=None, out=None):
         return out
     if K % 4:
         kp = (K + 3) // 4 * 4
-        a, w = _pad_k(a, kp), _pad_k(w, kp)
+        a, w = pad_k_cached(a, kp), pad_k_cached(w, kp)
     a = a if a.stride(1) == 1 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 else a.contiguous()
     w = w if w.stride(1) == 1 and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0 else w.contiguous()
     ev = GEMM_EVENTS
@@ -216,13 +243,16 @@ class LimbImage:
         self.buf, self.rows, self.cols, self.fmt, self.exp, self.amax = buf, rows, cols, fmt, exp, amax
 
 
-def limb_empty(rows, cols, device, fmt="bf16x3", zero_amax=True):
+def limb_empty(rows, cols, device, fmt="bf16x3", zero_amax=True, scales=None):
+    """scales: optional (2, rows) int32 tensor for the row exponents / row maxima of an f16x2
+    image (the maxima zeroed by the caller when a GEMM epilogue is going to collect them)."""
     q = "hd_limb_image_bytes" if fmt == "bf16x3" else "hd_limb_image_bytes_f16x2"
     nbytes = getattr(_lib.load(), q)(rows, cols)
     buf = torch.empty(max(nbytes // 4, 4), dtype=torch.int32, device=device)
     if fmt == "bf16x3":
         return LimbImage(buf, rows, cols)
-    scales = (torch.zeros if zero_amax else torch.empty)(2, max(rows, 1), dtype=torch.int32, device=device)
+    if scales is None:
+        scales = (torch.zeros if zero_amax else torch.empty)(2, max(rows, 1), dtype=torch.int32, device=device)
     return LimbImage(buf, rows, cols, fmt, scales[0], scales[1])
 
 
@@ -286,7 +316,7 @@ def _bias_absmax(b):
 
 
 def gemm_limbs(a, w, bias=None, epi=0, resid=None, want_f32=True, want_limbs=False, out=None, w_norm=None,
-               bias_max=None):
+               bias_max=None, out_scales=None):
     """epi(a @ w.T + bias) from limb images; returns (fp32 tensor or None, LimbImage or None).
     f16x2 with want_limbs: w_norm = max row 2-norm of w, bias_max = max|bias| (bounds of the output rows)."""
     M, K, N = a.rows, a.cols, w.rows
@@ -296,7 +326,7 @@ def gemm_limbs(a, w, bias=None, epi=0, resid=None, want_f32=True, want_limbs=Fal
     c = None
     if want_f32:
         c = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=dev)
-    cl = limb_empty(M, N, dev, fmt) if want_limbs else None
+    cl = limb_empty(M, N, dev, fmt, scales=out_scales) if want_limbs else None
     ldc = c.stride(0) if c is not None else (resid.stride(0) if resid is not None else N)
     if resid is not None and c is not None:
         assert resid.stride(0) == c.stride(0)
@@ -352,6 +382,9 @@ def linear_chain(x, layers):
     else:
         fmt = "f16x2" if GEMM_MODE == "f16x2" and all(epi in (0, 1) for _, _, epi in layers) else "bf16x3"
         a, xf = limb_pack(x, fmt), x
+    # f16x2: the row exponents / maxima of every intermediate image in one zero-filled allocation
+    sc = torch.zeros(len(layers) - 1, 2, max(a.rows, 1), dtype=torch.int32, device=a.buf.device) \
+        if fmt == "f16x2" and len(layers) > 1 else None
     for i, (w, b, epi) in enumerate(layers):
         last = i == len(layers) - 1
         need_f32 = last or layers[i + 1][2] == 2
@@ -361,7 +394,8 @@ def linear_chain(x, layers):
         wl, wn = weight_limbs(w, fmt)
         bd = None if b is None else b.detach()
         xf, a = gemm_limbs(a, wl, bd, epi=epi, resid=resid, want_f32=need_f32, want_limbs=not last, w_norm=wn,
-                           bias_max=_bias_absmax(b) if fmt == "f16x2" and not last else None)
+                           bias_max=_bias_absmax(b) if fmt == "f16x2" and not last else None,
+                           out_scales=sc[i] if sc is not None and not last else None)
     return xf
 
 
