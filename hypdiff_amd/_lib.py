@@ -71,6 +71,7 @@ SIGNATURES = {
     "hd_gemm_limbs_f32": [P, P, P, P, P, P, I64, I64, I64, I64, c_int, P],
     "hd_limb_pack_f16x2_f32": [P, I64, I64, I64, P, P, P, P],
     "hd_mlp_pack_input_f16x2": [P, c_int, P, c_int, c_double, P, P, P, I64, I64, P],
+    "hd_row_pack_f16x2_f32": [P, c_int, HdCurv, P, P, P, P, I64, I64, P],
     "hd_limb_unpack_f16x2_f32": [P, P, I64, I64, P, I64, P],
     "hd_gemm_f16x2_f32": [P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, c_int, c_float, c_float, P],
     "hd_gemm_tn_f32": [P, P, P, I64, I64, I64, I64, I64, I64, P, P],

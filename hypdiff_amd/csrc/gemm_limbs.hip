@@ -45,6 +45,7 @@
 // F.gelu of models/direction_diffusion.py:56-69, ddpm.py:9-41.
 #include "hd_common.cuh"
 #include "hd_gelu.cuh"
+#include "hd_manifold.cuh"
 #include "../../include/hypdiff.h"
 #include <stdlib.h>
 
@@ -172,25 +173,31 @@ __global__ __launch_bounds__(256) void limb_pack(const float* __restrict__ in, i
     }
 }
 
-// mlp input cat(x.float(), t[:,None]) (models/direction_diffusion.py:57-58) -> f16x2 limb image in one
-// pass over the latents: one wavefront per row, a lane owns the 8-column chunks lane, lane + 64, ...;
-// the row maximum is a wavefront reduction, so the row is read once and no fp32 copy is made.
-constexpr int kPackChunks = 3;                                    // chunks per lane: dim + 1 <= 1536
-template <typename TX>
-__global__ __launch_bounds__(256) void mlp_pack_f16x2(const TX* __restrict__ x, const void* __restrict__ t, int t_kind,
-                                                      float t_scalar, int rows, int dim, int nslab,
+// Row producers that write the f16x2 image of a GEMM operand directly, in one pass over the rows: one
+// wavefront per row, a lane owns the 8-column chunks lane, lane + 64, ...; the row maximum (and the
+// row norm, where the map needs one) is a wavefront reduction, so the row is read once and no fp32
+// copy of the operand is made.
+//   PACK_MLP     cat(x.float(), t[:,None])            models/direction_diffusion.py:57-58
+//   PACK_HB_LOG0 Hyperboloid.logmap0(x)               manifolds/hyperboloid.py:103-113 (operand of :122)
+//   PACK_NORM    x itself; also writes |x|_2 per row  manifolds/poincare.py:94-96
+enum PackMode { PACK_MLP = 0, PACK_HB_LOG0 = 1, PACK_NORM = 2 };
+constexpr int kPackChunks = 3;                                    // chunks per lane: cols <= 1536
+template <int MODE, typename TX>
+__global__ __launch_bounds__(256) void row_pack_f16x2(const TX* __restrict__ x, const void* __restrict__ t, int t_kind,
+                                                      float t_scalar, int rows, int dim, int nslab, Curv cv,
                                                       uint4* __restrict__ out, int* __restrict__ ex,
-                                                      unsigned* __restrict__ amax) {
+                                                      unsigned* __restrict__ amax, float* __restrict__ norms) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     constexpr int V = 16 / sizeof(TX);
     using VT = typename VecOf<TX>::type;
     const TX* xr = x + (int64_t)row * dim;
     const bool vec_ok = (reinterpret_cast<uintptr_t>(xr) & 15) == 0;
-    const float tv = t_kind == 0 ? (float)((const int64_t*)t)[row] : (t_kind == 1 ? ((const float*)t)[row] : t_scalar);
+    float tv = 0.f;
+    if constexpr (MODE == PACK_MLP)
+        tv = t_kind == 0 ? (float)((const int64_t*)t)[row] : (t_kind == 1 ? ((const float*)t)[row] : t_scalar);
     const int nchunk = nslab * 4;
     float v[kPackChunks][8];
-    float m = 0.f;
 #pragma unroll
     for (int q = 0; q < kPackChunks; ++q) {
         const int c0 = (lane + 64 * q) * 8;
@@ -206,12 +213,39 @@ __global__ __launch_bounds__(256) void mlp_pack_f16x2(const TX* __restrict__ x, 
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int c = c0 + e;
-                v[q][e] = c < dim ? (float)xr[c] : (c == dim ? tv : 0.f);
+                v[q][e] = c < dim ? (float)xr[c] : (MODE == PACK_MLP && c == dim ? tv : 0.f);
             }
         }
+    }
+    if constexpr (MODE != PACK_MLP) {
+        float ss = 0.f;
+#pragma unroll
+        for (int q = 0; q < kPackChunks; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (!(MODE == PACK_HB_LOG0 && q == 0 && e == 0 && lane == 0)) ss += v[q][e] * v[q][e];
+#pragma unroll
+        for (int off = 32; off; off >>= 1) ss += __shfl_xor(ss, off);
+        if constexpr (MODE == PACK_NORM) {
+            if (lane == 0) norms[row] = sqrtf(ss);
+        } else {
+            const float x0 = __shfl(v[0][0], 0);
+            const float sK = (float)cv.sK;
+            const float n = clamp_min(hd_sqrt(ss), (float)kMinNorm);
+            const float theta = clamp_min(x0 / sK, (float)(1.0 + Lim<float>::hb_eps));
+            const float f = sK * arcosh_ref(theta) / n;
+#pragma unroll
+            for (int q = 0; q < kPackChunks; ++q)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[q][e] *= f;
+            if (lane == 0) v[0][0] = 0.f;
+        }
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int q = 0; q < kPackChunks; ++q)
 #pragma unroll
         for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[q][e]));
-    }
 #pragma unroll
     for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
     const int e_row = exp_for(m, 15);
@@ -637,12 +671,36 @@ extern "C" int hd_mlp_pack_input_f16x2(const void* x, int x_dtype, const void* t
     const int nslab = (int)((dim + 1 + 31) / 32);
     const dim3 grid((unsigned)((rows + 3) / 4));
     if (x_dtype)
-        mlp_pack_f16x2<double><<<grid, 256, 0, (hipStream_t)st>>>((const double*)x, t, t_kind, (float)t_scalar, (int)rows,
-                                                                  (int)dim, nslab, (uint4*)out, (int*)ex, (unsigned*)amax);
+        row_pack_f16x2<PACK_MLP, double><<<grid, 256, 0, (hipStream_t)st>>>(
+            (const double*)x, t, t_kind, (float)t_scalar, (int)rows, (int)dim, nslab, Curv{}, (uint4*)out, (int*)ex,
+            (unsigned*)amax, nullptr);
     else
-        mlp_pack_f16x2<float><<<grid, 256, 0, (hipStream_t)st>>>((const float*)x, t, t_kind, (float)t_scalar, (int)rows,
-                                                                 (int)dim, nslab, (uint4*)out, (int*)ex, (unsigned*)amax);
+        row_pack_f16x2<PACK_MLP, float><<<grid, 256, 0, (hipStream_t)st>>>(
+            (const float*)x, t, t_kind, (float)t_scalar, (int)rows, (int)dim, nslab, Curv{}, (uint4*)out, (int*)ex,
+            (unsigned*)amax, nullptr);
     return check_launch("hd_mlp_pack_input_f16x2");
+}
+
+extern "C" int hd_row_pack_f16x2_f32(const void* x, int mode, hd_curv c, void* out, void* ex, void* amax, void* norms,
+                                     int64_t rows, int64_t dim, void* st) {
+    HD_REQUIRE(rows >= 0 && dim >= 1 && dim <= 64 * 8 * kPackChunks, "hd_row_pack_f16x2_f32: dim out of range (<= %d)",
+               64 * 8 * kPackChunks);
+    HD_REQUIRE(mode == PACK_HB_LOG0 || mode == PACK_NORM, "hd_row_pack_f16x2_f32: mode must be 1 (hyperboloid logmap0) or 2 (rows + norms)");
+    if (rows == 0) return HD_OK;
+    HD_REQUIRE(x && out && ex && amax && is_aligned16(out) && (mode != PACK_NORM || norms),
+               "hd_row_pack_f16x2_f32: null or misaligned pointer");
+    HD_REQUIRE(rows < (1LL << 31), "hd_row_pack_f16x2_f32: size exceeds int32");
+    const int nslab = (int)((dim + 31) / 32);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    const Curv cv{c.c, c.sqrt_c, c.K, c.sqrt_K};
+    if (mode == PACK_HB_LOG0)
+        row_pack_f16x2<PACK_HB_LOG0, float><<<grid, 256, 0, (hipStream_t)st>>>(
+            (const float*)x, nullptr, 2, 0.f, (int)rows, (int)dim, nslab, cv, (uint4*)out, (int*)ex, (unsigned*)amax, nullptr);
+    else
+        row_pack_f16x2<PACK_NORM, float><<<grid, 256, 0, (hipStream_t)st>>>(
+            (const float*)x, nullptr, 2, 0.f, (int)rows, (int)dim, nslab, cv, (uint4*)out, (int*)ex, (unsigned*)amax,
+            (float*)norms);
+    return check_launch("hd_row_pack_f16x2_f32");
 }
 
 extern "C" int hd_limb_unpack_f32(const void* in, int64_t rows, int64_t cols, void* out, int64_t ld, void* st) {

@@ -47,8 +47,11 @@ class Hyperboloid(Manifold):
         if m.dtype != x2.dtype:
             m = m.to(x2.dtype)
         m = ops.match_padded(x2, m)
-        u = ops.map1("hd_hb_logmap0", x2, c)
-        mu = ops.gemm(u, m)
+        if ops.use_f16x2(x2, m):
+            # logmap0 writes the f16x2 limb image of the GEMM operand directly (one pass over x)
+            mu, _ = ops.gemm_limbs(ops.row_pack(x2, 1, c), ops.weight_limbs(m, "f16x2")[0])
+        else:
+            mu = ops.gemm(ops.map1("hd_hb_logmap0", x2, c), m)
         out = torch.empty_like(mu)
         ops._lib.call("hd_hb_linear_epilogue" + ops._sfx(mu), ops._p(mu), ops._p(out), mu.shape[0], mu.shape[1],
                       ops.curv(c), _flags, ops._stream())

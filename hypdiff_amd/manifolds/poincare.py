@@ -58,8 +58,12 @@ class PoincareBall(Manifold):
         if m.dtype != x2.dtype:
             m = m.to(x2.dtype)
         m = ops.match_padded(x2, m)
-        xn = ops.rownorm(x2)
-        mx = ops.gemm(x2, m)
+        if ops.use_f16x2(x2, m):
+            img, xn = ops.row_pack(x2, 2)       # row norms and the f16x2 operand image in one pass over x
+            mx, _ = ops.gemm_limbs(img, ops.weight_limbs(m, "f16x2")[0])
+        else:
+            xn = ops.rownorm(x2)
+            mx = ops.gemm(x2, m)
         out = torch.empty_like(mx)
         ops._lib.call("hd_pb_matvec_epilogue" + ops._sfx(mx), ops._p(mx), ops._p(xn), ops._p(out), mx.shape[0],
                       mx.shape[1], ops.curv(c), _flags, ops._stream())

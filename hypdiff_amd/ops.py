@@ -282,17 +282,21 @@ def limb_unpack(img):
 _wlimb_cache = {}
 
 
-def weight_limbs(w, fmt="bf16x3"):
-    """(LimbImage, max row 2-norm) of a weight matrix, rebuilt when the parameter changes (keyed
-    like `curv`).  The norm (f16x2 only: one read-back per parameter version) feeds the row bound
-    of the products written as f16x2 images."""
+def weight_limbs(w, fmt="bf16x3", need_norm=False):
+    """(LimbImage, max row 2-norm or None) of a weight matrix, rebuilt when the parameter changes
+    (keyed like `curv`).  The norm (f16x2 chains only: one read-back per parameter version) feeds
+    the row bound of the products written as f16x2 images."""
     key = (id(w), fmt)
     hit = _wlimb_cache.get(key)
     if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == w.data_ptr():
-        return hit[3]
+        img, wn = hit[3]
+        if need_norm and wn is None:
+            wn = float(w.detach().double().norm(dim=1).max())
+            _wlimb_cache[key] = hit[:3] + ((img, wn),)
+        return img, wn
     wd = w.detach()
     img = limb_pack(wd if wd.stride(1) == 1 else wd.contiguous(), fmt)
-    wn = float(wd.double().norm(dim=1).max()) if fmt == "f16x2" else 0.0
+    wn = float(wd.double().norm(dim=1).max()) if need_norm else None
     if len(_wlimb_cache) > 256:
         _wlimb_cache.clear()
     _wlimb_cache[key] = (weakref.ref(w), w._version, w.data_ptr(), (img, wn))
@@ -359,6 +363,29 @@ def gemm_limbs(a, w, bias=None, epi=0, resid=None, want_f32=True, want_limbs=Fal
     return c, cl
 
 
+ROW_PACK_MAX_DIM = 1536
+
+
+def row_pack(x2, mode, c=None):
+    """fp32 rows -> f16x2 LimbImage in one pass (hd_row_pack_f16x2_f32): mode 1 = Hyperboloid
+    logmap0(x, c), mode 2 = x itself (returns (image, row norms))."""
+    _dev(x2)
+    assert x2.dim() == 2 and x2.dtype == torch.float32 and x2.is_contiguous() and x2.shape[1] <= ROW_PACK_MAX_DIM
+    n, d = x2.shape
+    img = limb_empty(n, d, x2.device, "f16x2", zero_amax=False)
+    norms = torch.empty(n, dtype=torch.float32, device=x2.device) if mode == 2 else None
+    _lib.call("hd_row_pack_f16x2_f32", _p(x2), mode, curv(c if c is not None else 1.0), _p(img.buf), _p(img.exp),
+              _p(img.amax), _p(norms), n, d, _stream())
+    return (img, norms) if mode == 2 else img
+
+
+def use_f16x2(x2, m):
+    """HypLinear's x @ W^T goes through the f16x2 limb kernel (inference, fp32, rows short enough
+    for the one-pass row producers)."""
+    return (GEMM_MODE == "f16x2" and x2.dtype == torch.float32 and m.dtype == torch.float32
+            and x2.shape[1] <= ROW_PACK_MAX_DIM and x2.shape[0] > 0)
+
+
 def linear_chain(x, layers):
     """Inference-only stack of nn.Linear layers: layers = [(weight, bias, epi), ...] with epi 0
     none, 1 erf-GELU, 2 x + GELU(layer(x)) (ddpm.py:20-22); x fp32 (M, K) on the device.
@@ -391,7 +418,7 @@ def linear_chain(x, layers):
         resid = None
         if epi == 2:
             resid = xf if xf.is_contiguous() else xf.contiguous()
-        wl, wn = weight_limbs(w, fmt)
+        wl, wn = weight_limbs(w, fmt, need_norm=fmt == "f16x2" and not last)
         bd = None if b is None else b.detach()
         xf, a = gemm_limbs(a, wl, bd, epi=epi, resid=resid, want_f32=need_f32, want_limbs=not last, w_norm=wn,
                            bias_max=_bias_absmax(b) if fmt == "f16x2" and not last else None,

@@ -236,6 +236,11 @@ int hd_limb_unpack_f16x2_f32(const void* in, const void* ex, int64_t rows, int64
  * hd_mlp_pack_input; dim + 1 <= 1536. */
 int hd_mlp_pack_input_f16x2(const void* x, int x_dtype, const void* t, int t_kind, double t_scalar, void* out,
                             void* ex, void* amax, int64_t rows, int64_t dim, void* stream);
+/* GEMM operands of HypLinear written directly as f16x2 images, one pass over the rows (dim <= 1536):
+ * mode 1 = Hyperboloid.logmap0(x, c) (manifolds/hyperboloid.py:103-113, the operand of :122),
+ * mode 2 = x itself, with norms[row] = |x|_2 (manifolds/poincare.py:94-96). */
+int hd_row_pack_f16x2_f32(const void* x, int mode, hd_curv c, void* out, void* ex, void* amax, void* norms,
+                          int64_t rows, int64_t dim, void* stream);
 int hd_gemm_f16x2_f32(const void* A, const void* ea, const void* amax_a, const void* W, const void* ew,
                       const void* bias, void* C, void* CL, void* eo, void* amax_o, int64_t M, int64_t N, int64_t K,
                       int64_t ldc, int epi, float bound_mul, float bound_add, void* stream);
