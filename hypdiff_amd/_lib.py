@@ -60,6 +60,9 @@ SIGNATURES = {
     "hd_pb_edge_decode_bwd*": [P, P, I64, P, P, I64, I64, HdCurv, c_int, c_double, c_double, P],
     "hd_hb_edge_decode_bwd*": [P, P, I64, P, P, I64, I64, HdCurv, c_int, c_double, c_double, P],
     "hd_csr_from_coo": [P, P, I64, I64, I64, P, P, P, P],
+    "hd_adj_count": [P, P, I64, P, P, P],
+    "hd_adj_fill": [P, P, P, I64, P, c_int, P, P, P, P],
+    "hd_feat_normalize": [P, c_int, I64, I64, P, P],
     "hd_spmm_csr*": [P, P, P, P, P, I64, I64, P, I64, P],
     "hd_pb_agg*": _agg, "hd_hb_agg*": _agg,
     "hd_gemm_f32": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, c_int, P],

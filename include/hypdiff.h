@@ -157,6 +157,19 @@ HD_DECL2(hd_rownorm, const void* x, void* out, int64_t rows, int64_t dim, void* 
  * out of range. */
 int hd_csr_from_coo(const int64_t* row, const int64_t* col_in, int64_t nnz, int64_t n_rows, int64_t n_cols,
                     int32_t* rowptr, int32_t* col, int32_t* flags, void* stream);
+/* Adjacency preprocessing on the device, utils/data_utils.py:103-133 (`process`): adj_train as a CSR
+ * with ascending columns per row (int64 rowptr (n+1) / col, optional fp64 values, null = ones) ->
+ * normalize(adj + I) = D^-1 (A + I) (fp64, 1/0 -> 0; normalize = 0 writes A + I unscaled -- the reference
+ * adds the identity only when it normalises, so its drop-in always passes 1) as the COO the reference's
+ * .tocoo() yields: row-major, columns descending inside a row (scipy's sparse product r_mat_inv.dot(mx)
+ * reverses the merged row), int64 indices, fp32 values.  hd_adj_count writes every
+ * output row's length (flags[0]: bit0 columns not strictly ascending, bit1 index out of range); the
+ * caller prefix-sums them into out_ptr (n+1, starting at 0) and calls hd_adj_fill.
+ * hd_feat_normalize: features <- normalize(features) (:106-107), fp32 out. */
+int hd_adj_count(const int64_t* rowptr, const int64_t* col, int64_t n, int64_t* counts, int32_t* flags, void* stream);
+int hd_adj_fill(const int64_t* rowptr, const int64_t* col, const double* val, int64_t n, const int64_t* out_ptr,
+                int normalize, int64_t* out_row, int64_t* out_col, float* out_val, void* stream);
+int hd_feat_normalize(const void* x, int x_dtype, int64_t rows, int64_t dim, float* out, void* stream);
 /* plain torch.spmm(adj, x) :150.  long_rows (n_long entries, may be NULL/0): ids of the rows
  * with more than 512 stored entries (power-law hubs); each of them is summed by a whole
  * workgroup in 8 fixed slices instead of by one lane group. */

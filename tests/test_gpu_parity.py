@@ -148,6 +148,48 @@ def test_csr_bit_exact(golden, kind, n):
     assert np.array_equal(H(csr.val), val)
 
 
+@pytest.mark.parametrize("kind,n", GRAPHS)
+def test_device_process_bit_exact(golden, kind, n):
+    """utils/data_utils.process on the device == the COO the reference's own process() produced from the
+    same adj_train (indices, order and fp32 values bit for bit); identity features stay the identity."""
+    import scipy.sparse as sp
+    from hypdiff_amd.utils import data_utils
+    g = golden("layers")
+    k0 = f"{kind}{n}/"
+    indptr, indices = g[k0 + "adj_train_indptr"], g[k0 + "adj_train_indices"]
+    adj_train = sp.csr_matrix((np.ones(len(indices)), indices, indptr), shape=(n, n))
+    adj_t, feats = data_utils.process(adj_train, sp.eye(n).tocsr(), 1, 1)
+    assert adj_t.is_sparse and adj_t.device.type == "cuda"
+    assert np.array_equal(H(adj_t._indices()), g[k0 + "coo_indices"])
+    assert np.array_equal(H(adj_t._values()), g[k0 + "coo_values"])
+    assert np.array_equal(H(feats), np.eye(n, dtype=np.float32))
+    # the same from device index arrays (no scipy on the way), isolated nodes and explicit self loops
+    t2 = data_utils.normalize_adj((torch.from_numpy(indptr.astype(np.int64)), torch.from_numpy(indices.astype(np.int64))))
+    assert np.array_equal(H(t2._values()), g[k0 + "coo_values"])
+    rs = np.random.RandomState(n)
+    a = sp.random(60, 60, density=0.05, random_state=rs, format="csr")
+    a.data[:] = 1.0
+    a = ((a + a.T) > 0).astype(np.float64).tolil()
+    a[3, 3] = 1.0
+    a[7, :] = 0
+    a[:, 7] = 0
+    a = a.tocsr()
+    idx, val, shape = adjacency.process_adj(a)
+    got = data_utils.normalize_adj(a)
+    assert np.array_equal(H(got._indices()), idx) and np.array_equal(H(got._values()), val)
+    w = sp.random(40, 40, density=0.1, random_state=rs, format="csr")       # weighted entries, fp64 row sums
+    idx, val, shape = adjacency.process_adj(w)
+    got = data_utils.normalize_adj(w)
+    assert np.array_equal(H(got._indices()), idx)
+    assert_close(H(got._values()), val, rtol=2e-7, what="weighted normalize")
+    f = rs.rand(33, 70)
+    f[5] = 0.0
+    want = adjacency.row_normalize(sp.csr_matrix(f)).toarray().astype(np.float32)
+    assert_close(H(data_utils.normalize_features(f)), want, rtol=2e-7, what="normalize_features")
+    with pytest.raises(ValueError):
+        data_utils.normalize_adj((torch.tensor([0, 2, 2]), torch.tensor([1, 0])))
+
+
 def test_csr_unsorted_empty_rows_and_bounds():
     from hypdiff_amd import ops
     rs = np.random.RandomState(3)
