@@ -59,24 +59,29 @@ def gemm_summary(events):
     return per
 
 
-def timed_steps(w, T, steps, warmup, barrier, ops, dist, device):
+def timed_steps(w, T, steps, warmup, barrier, ops, dist, device, instrument=False):
+    """W untimed + K timed steps between barriers.  instrument=False: nothing but the step's own
+    launches goes to the stream (the headline).  instrument=True: every GEMM launch and the two
+    phases of a step are bracketed by HIP events on the launch stream -- each record is a packet
+    of its own in the queue and the 17 per step cost about 8 % of a 0.6 ms step, so the per-kernel
+    durations of the roofline come from a second pass over the same K steps."""
     with torch.no_grad():
         for i in range(warmup):
             one_step(w, T - 1 - (i % T))
         barrier()
-        ops.GEMM_EVENTS = []
-        phase = []
+        ops.GEMM_EVENTS = [] if instrument else None
+        phase = [] if instrument else None
         t0 = time.perf_counter()
         for i in range(steps):
             one_step(w, T - 1 - (i % T), phase)
         barrier()
         elapsed = time.perf_counter() - t0
-        events, ops.GEMM_EVENTS = ops.GEMM_EVENTS, None
+        events, ops.GEMM_EVENTS = ops.GEMM_EVENTS or [], None
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    return elapsed, events, phase
+    return elapsed, events, phase or []
 
 
 def build_workload(dim, T, seed, device):
@@ -201,8 +206,8 @@ def train_leg(w, dim, device, steps, warmup, barrier, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--timesteps", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -234,7 +239,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    elapsed, events, phase = timed_steps(w, T, a.steps, a.warmup, barrier, ops, dist, device)
+    elapsed, _, _ = timed_steps(w, T, a.steps, a.warmup, barrier, ops, dist, device)
+    el_inst, events, phase = timed_steps(w, T, a.steps, min(a.warmup, 3), barrier, ops, dist, device, instrument=True)
 
     # dominant kernel: the fp32 GEMM of the denoiser / HypLinear (live HIP-event timing per launch)
     per = gemm_summary(events)
@@ -274,6 +280,9 @@ def main():
                      "traffic_unit": "HBM bytes per launch (mean)", "traffic_source": traffic_src,
                      "peak_note": PEAK_NOTES[dom],
                      "achieved_over_f32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS,
+                     "timing": "HIP events on the launch stream around every GEMM launch of a second, instrumented "
+                               "pass over the same K steps (%.4f ms per step with the 17 event records per step in "
+                               "the queue; the headline K steps carry none)" % (el_inst / a.steps * 1e3),
                      "algorithmic_bytes_per_launch": d["bytes"] / max(1, d["launches"]), "launches": d["launches"],
                      "kernel_ms_per_step": d["ms"] / a.steps, "all_gemm_ms_per_step": gemm_ms / a.steps,
                      "other_gemm_kernels": {k: {"launches": v["launches"], "TFLOP/s": v["flops"] / (v["ms"] * 1e-3) / 1e12,
@@ -286,7 +295,7 @@ def main():
     out["breakdown"] = {"encode_ms": enc_ms, "encode_nodes_per_s_per_gpu": w["n"] / (enc_ms * 1e-3) if enc_ms else None,
                         "p_sample_ms": dif_ms,
                         "ddpm_node_steps_per_s_per_gpu": w["n"] / (dif_ms * 1e-3) if dif_ms else None,
-                        "note": "HIP-event time of the two phases of one step on rank 0 (SURVEY.md 8d)"}
+                        "note": "HIP-event time of the two phases of one step on rank 0, instrumented pass (SURVEY.md 8d)"}
     if not a.no_exact_leg:
         # the same K steps under the other fp32 GEMM kernels, for comparison
         mode = ops.GEMM_MODE
@@ -296,7 +305,8 @@ def main():
                 if m2 == mode:
                     continue
                 ops.GEMM_MODE = m2
-                el2, ev2, _ = timed_steps(w, T, a.steps, min(a.warmup, 3), barrier, ops, dist, device)
+                el2, _, _ = timed_steps(w, T, a.steps, min(a.warmup, 3), barrier, ops, dist, device)
+                _, ev2, _ = timed_steps(w, T, a.steps, 1, barrier, ops, dist, device, instrument=True)
                 per2 = gemm_summary(ev2)
                 k2 = max(per2, key=lambda k: per2[k]["ms"])
                 ach2 = per2[k2]["flops"] / (per2[k2]["ms"] * 1e-3) / 1e12

@@ -95,11 +95,13 @@ __device__ __forceinline__ void split4_f16(const float4 v, uint2& h, uint2& l) {
     l.y = pk_f16(v.z - hf_lo(h.y), v.w - hf_hi(h.y));
 }
 
-// row exponent e with bound * 2^e in [2^(top-1), 2^top); 0 for a zero / non-finite bound
+// row exponent e with bound * 2^e in [2^(top-1), 2^top); 0 for a zero / NaN bound; a bound that
+// overflowed fp32 is taken as 2^128, so every finite value of the row still fits fp16
 __device__ __forceinline__ int exp_for(float bound, int top) {
-    if (!(bound > 0.f) || bound > 3.0e38f) return 0;
+    if (!(bound > 0.f)) return 0;
+    if (bound > 3.0e38f) return top - 128;
     const int e = top - __builtin_amdgcn_frexp_expf(bound);         // bound < 2^frexp_exp
-    return e < -100 ? -100 : (e > 100 ? 100 : e);
+    return e < -120 ? -120 : (e > 120 ? 120 : e);
 }
 
 __device__ __forceinline__ void glds16(const uint4* g, uint4* l) {

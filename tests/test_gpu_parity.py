@@ -190,6 +190,47 @@ def test_device_process_bit_exact(golden, kind, n):
         data_utils.normalize_adj((torch.tensor([0, 2, 2]), torch.tensor([1, 0])))
 
 
+def test_f16x2_edge_cases():
+    """Empty operands, rows past the one-pass producers' limit, non-finite inputs and rows whose bound
+    overflows fp32 (hd_gemm_f16x2_f32 / hd_row_pack_f16x2_f32 / hd_mlp_pack_input_f16x2)."""
+    from hypdiff_amd import ops
+    from hypdiff_amd.utils import data_utils
+    rs = np.random.RandomState(11)
+    w = G(rs.standard_normal((40, 36)).astype(np.float32))
+    wl = ops.limb_pack(w, "f16x2")
+    e = ops.limb_pack(torch.zeros(0, 36, device="cuda"), "f16x2")
+    c, cl = ops.gemm_limbs(e, wl, want_f32=True, want_limbs=True, w_norm=1.0, bias_max=0.0)
+    assert c.shape == (0, 40) and cl.rows == 0
+    assert ops.row_pack(torch.zeros(0, 36, device="cuda"), 1, 1.0).rows == 0
+    with pytest.raises(RuntimeError):
+        ops._lib.call("hd_row_pack_f16x2_f32", None, 1, ops.curv(1.0), None, None, None, None, 4, 2000, ops._stream())
+    with pytest.raises(RuntimeError):
+        ops._lib.call("hd_gemm_f16x2_f32", None, None, None, None, None, None, None, None, None, None, 4, 4, 4, 4, 2,
+                      0.0, 0.0, ops._stream())
+    # a zero row, a row of 1e37 (its bound overflows fp32: exponent falls back to 2^-114), an inf and a NaN
+    a = rs.standard_normal((6, 36)).astype(np.float32)
+    a[1] = 0.0
+    a[2] *= 1e37 / np.abs(a[2]).max()
+    a[3, 5] = np.inf
+    a[4, 7] = np.nan
+    wn = float(w.double().norm(dim=1).max())
+    c, cl = ops.gemm_limbs(ops.limb_pack(G(a), "f16x2"), wl, want_f32=True, want_limbs=True, w_norm=wn, bias_max=0.0)
+    hc = H(c)
+    ref = a.astype(np.float64) @ H(w).astype(np.float64).T
+    mag = np.abs(a).astype(np.float64) @ np.abs(H(w)).astype(np.float64).T
+    for r in (0, 1, 2, 5):
+        assert np.all(np.abs(hc[r] - ref[r]) <= 2e-6 * mag[r] + 1e-30), r
+    assert not np.isfinite(hc[3]).any() and np.isnan(hc[4]).all()
+    back = H(ops.limb_unpack(cl))
+    for r in (0, 1, 5):
+        assert np.all(np.abs(back[r] - hc[r]) <= 2.0 ** -20 * np.abs(hc[r]).max() + 1e-30), r
+    assert np.all(np.isfinite(back[2])) and np.all(np.abs(back[2] - hc[2]) <= 2.0 ** -9 * np.abs(hc[2]).max())
+    # empty graph through the device preprocessing
+    import scipy.sparse as sp
+    t = data_utils.normalize_adj(sp.csr_matrix((3, 3)))
+    assert np.array_equal(H(t._indices()), np.array([[0, 1, 2], [0, 1, 2]])) and np.array_equal(H(t._values()), np.ones(3, np.float32))
+
+
 def test_csr_unsorted_empty_rows_and_bounds():
     from hypdiff_amd import ops
     rs = np.random.RandomState(3)
