@@ -331,17 +331,24 @@ __device__ __forceinline__ void store_quad(float v[4], int m, int mloc, int nb, 
                                            int epi, const float* __restrict__ bias, const float* __restrict__ resid,
                                            float* __restrict__ C, uint4* __restrict__ CL, size_t cl_tile_base,
                                            int eo_m, float& rmax) {
+    {
+        float x[4], g[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int n = nb + e;
-        float x = 0.f;
-        if (n < N) {
-            x = v[e] + (bias ? bias[n] : 0.f);
-            if (epi == 1) x = gelu_erf(x);
-            else if (epi == 2) x = resid[(size_t)m * ldc + n] + gelu_erf(x);
-            if constexpr (F16) rmax = fmaxf(rmax, fabsf(x));
+        for (int e = 0; e < 4; ++e) x[e] = v[e] + ((bias && nb + e < N) ? bias[nb + e] : 0.f);
+        if (epi != 0) {                                       // erf-GELU on the packed fp32 pipe, two at a time
+            const hd_f32x2 g01 = gelu_erf2(hd_f32x2{x[0], x[1]}), g23 = gelu_erf2(hd_f32x2{x[2], x[3]});
+            g[0] = g01.x; g[1] = g01.y; g[2] = g23.x; g[3] = g23.y;
         }
-        v[e] = x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = nb + e;
+            float y = 0.f;
+            if (n < N) {
+                y = epi == 0 ? x[e] : (epi == 1 ? g[e] : resid[(size_t)m * ldc + n] + g[e]);
+                if constexpr (F16) rmax = fmaxf(rmax, fabsf(y));
+            }
+            v[e] = y;
+        }
     }
     if (C) {
         float* o = C + (size_t)m * ldc + nb;

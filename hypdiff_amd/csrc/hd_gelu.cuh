@@ -30,6 +30,34 @@ __device__ __forceinline__ float erf_fast(float a) {
     return t > 0.927734375f ? r : q;
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
+// Two at a time on the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of
+// FMAs per issue): the same operations in the same order as erf_fast / gelu_erf, so the results are bit
+// identical; only exp and the selects stay scalar.  The GEMM write-outs are VALU-bound on this.
+typedef float hd_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ hd_f32x2 gelu_erf2(hd_f32x2 x) {
+    const hd_f32x2 a = x * 0.70710678118654752440f;
+    const hd_f32x2 t = {fabsf(a.x), fabsf(a.y)}, s = a * a;
+    auto fma2 = [](hd_f32x2 p, hd_f32x2 q, hd_f32x2 c) { return __builtin_elementwise_fma(p, q, c); };
+    auto k = [](float c) { return hd_f32x2{c, c}; };
+    hd_f32x2 r = fma2(k(-1.72853470e-5f), t, k(3.83197126e-4f));
+    const hd_f32x2 u = fma2(k(-3.88396438e-3f), t, k(2.42546219e-2f));
+    r = fma2(r, s, u);
+    r = fma2(r, t, k(-1.06777877e-1f));
+    r = fma2(r, t, k(-6.34846687e-1f));
+    r = fma2(r, t, k(-1.28717512e-1f));
+    r = fma2(r, t, -t);
+    r = hd_f32x2{1.0f - __expf(r.x), 1.0f - __expf(r.y)};
+    r = hd_f32x2{copysignf(r.x, a.x), copysignf(r.y, a.y)};
+    hd_f32x2 q = k(-5.96761703e-4f);
+    q = fma2(q, s, k(4.99119423e-3f));
+    q = fma2(q, s, k(-2.67681349e-2f));
+    q = fma2(q, s, k(1.12819925e-1f));
+    q = fma2(q, s, k(-3.76125336e-1f));
+    q = fma2(q, s, k(1.28379166e-1f));
+    q = fma2(q, a, a);
+    const hd_f32x2 e = {t.x > 0.927734375f ? r.x : q.x, t.y > 0.927734375f ? r.y : q.y};
+    return (x * 0.5f) * (e + 1.0f);
+}
 // d/dx of the exact-erf GELU: Phi(x) + x * phi(x)
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     return 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
