@@ -2,6 +2,7 @@
 // Memory-bound kernels: every row is read once and written once; all norms, clamps,
 // artanh/arcosh and rescales of a composite map happen in registers in between.
 #include "hd_rowkernels.cuh"
+#include <stdlib.h>
 #include "../../include/hypdiff.h"
 
 using namespace hd;
@@ -194,3 +195,136 @@ HD_DECODE(hd_hb_edge_decode, HB)
     }
 HD_EPI(float, f32)
 HD_EPI(double, f64)
+
+// ---- HypLinear on the hyperboloid with a narrow input (d_in <= 64), one kernel --------------------
+// layers/hyp_layers.py:98-103 + manifolds/hyperboloid.py:103-123: logmap0(x) -> u W^T -> expmap0 (-> proj
+// -> logmap0).  With a few dozen input columns the contraction is a handful of FMAs per output (the first
+// HGCN layer of the graph-set configs: 21 features -> 512), so the three launches of the wide path (operand
+// producer, matrix-core GEMM, row tail) spend their time on launch ramps and on writing / re-reading mu.
+// Here a wavefront owns R rows: it reads x, takes logmap0, accumulates mu = u W^T as an fp32 fma chain over
+// k against W^T ((d_in, d_out) row-major, a few tens of KB: every wavefront streams it from L2 with 16-byte
+// loads, each reused for the R rows), applies the row tail to the accumulators (they already sit in the
+// row-tile layout of the row kernels) and writes the result: x is read once, the output written once,
+// nothing in between touches memory.
+namespace {
+
+// expmap0 (-> proj) (-> logmap0) of a row whose spatial sum of squares is s2, as ONE factor f on the spatial
+// part and the new time coordinate t0 (same clamp order as HB<T>::expmap0 / proj / logmap0; the norm of an
+// already scaled row is taken analytically, |f x| = f |x|, as hyp_act_homog does: rounding-level difference).
+__device__ __forceinline__ void hb_linear_tail_scalars(float s2, int flags, const Curv& cv, float& f, float& t0) {
+    const float sK = (float)cv.sK;
+    const float n0 = hd_sqrt(s2);
+    const float n = clamp_min(n0, (float)kMinNorm);
+    float shv, chv;
+    sinhcosh15(n / sK, shv, chv);
+    const float f1 = sK * shv / n;
+    const float m1 = f1 * n0;
+    const float x0 = hd_sqrt(clamp_min((float)cv.K + m1 * m1, (float)Lim<float>::hb_eps));
+    f = f1;
+    t0 = x0;
+    if (flags & 2) {
+        const float n2 = clamp_min(m1, (float)kMinNorm);
+        const float th = clamp_min(x0 / sK, (float)(1.0 + Lim<float>::hb_eps));
+        f = f1 * (sK * arcosh_ref(th) / n2);
+        t0 = 0.f;
+    }
+}
+
+__device__ __forceinline__ float lane_get(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+// The per-row scalar chains (logmap0's arcosh, the tail's sinh / cosh / arcosh: ~50 quarter-rate
+// transcendental issues per row) are wavefront-uniform in the row kernels, i.e. computed 64 times over.
+// Here a wavefront owns R rows and evaluates each chain ONCE for all of them, row r in lane r, then hands
+// the factors back with v_readlane: the kernel is bound by exactly this VALU work otherwise.
+template <int R>
+__global__ __launch_bounds__(256) void hb_linear_smallk(const float* __restrict__ x, const float* __restrict__ Wt,
+                                                        float* __restrict__ out, int64_t n, int K, int N,
+                                                        Curv cv, int flags) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    using TL = Tile<float, 64, 4, 8>;
+    const float sK = (float)cv.sK;
+    const int c0 = 4 * lane, c1 = 256 + 4 * lane;
+    for (int64_t base = ((int64_t)blockIdx.x * 4 + wave) * R; base < n; base += (int64_t)gridDim.x * 4 * R) {
+        float xv[R], u[R];
+        float ss_l = 0.f, x0_l = 0.f;                        // lane r: row r's spatial |x|^2 and time coordinate
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = base + r < n ? base + r : n - 1;
+            xv[r] = lane < K ? x[row * K + lane] : 0.f;
+            const float ss = group_sum<64>(lane >= 1 ? xv[r] * xv[r] : 0.f);     // hyperboloid.py:105-106
+            const float x0 = lane_bcast0(xv[r]);
+            if (lane == r) { ss_l = ss; x0_l = x0; }
+        }
+        {                                                   // logmap0 (hyperboloid.py:103-113), R rows at once
+            const float nrm = clamp_min(hd_sqrt(ss_l), (float)kMinNorm);
+            const float theta = clamp_min(x0_l / sK, (float)(1.0 + Lim<float>::hb_eps));
+            const float f_l = sK * arcosh_ref(theta) / nrm;
+#pragma unroll
+            for (int r = 0; r < R; ++r) u[r] = lane == 0 ? 0.f : xv[r] * lane_get(f_l, r);
+        }
+        TL acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            acc[r].init(N);
+            acc[r].zero();
+        }
+#pragma unroll 4
+        for (int k = 0; k < K; ++k) {
+            const float* wk = Wt + (int64_t)k * N;
+            float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
+            if (c0 < N) w0 = *reinterpret_cast<const float4*>(wk + c0);
+            if (c1 < N) w1 = *reinterpret_cast<const float4*>(wk + c1);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float uk = lane_get(u[r], k);
+                acc[r].v[0] = fmaf(uk, w0.x, acc[r].v[0]);
+                acc[r].v[1] = fmaf(uk, w0.y, acc[r].v[1]);
+                acc[r].v[2] = fmaf(uk, w0.z, acc[r].v[2]);
+                acc[r].v[3] = fmaf(uk, w0.w, acc[r].v[3]);
+                acc[r].v[4] = fmaf(uk, w1.x, acc[r].v[4]);
+                acc[r].v[5] = fmaf(uk, w1.y, acc[r].v[5]);
+                acc[r].v[6] = fmaf(uk, w1.z, acc[r].v[6]);
+                acc[r].v[7] = fmaf(uk, w1.w, acc[r].v[7]);
+            }
+        }
+        float s2_l = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float s2 = acc[r].sumsq(1);
+            if (lane == r) s2_l = s2;
+        }
+        float f_l, t0_l;
+        hb_linear_tail_scalars(s2_l, flags, cv, f_l, t0_l);  // expmap0 (-> proj) (-> logmap0), R rows at once
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = base + r;
+            acc[r].scale(lane_get(f_l, r), 1);
+            acc[r].set_first(lane_get(t0_l, r));
+            if (row < n) acc[r].store(out + row * N);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int hd_hb_linear_smallk_f32(const void* x, const void* Wt, void* out, int64_t rows, int64_t d_in,
+                                       int64_t d_out, hd_curv c, int flags, void* st) {
+    HD_REQUIRE(rows >= 0 && d_in >= 1 && d_in <= 64 && d_out >= 4 && d_out <= 512 && d_out % 4 == 0,
+               "hd_hb_linear_smallk_f32: shape outside the fused path (d_in <= 64, d_out <= 512 and a multiple of 4)");
+    if (rows == 0) return HD_OK;
+    HD_REQUIRE(x && Wt && out && is_aligned16(out) && is_aligned16(Wt), "hd_hb_linear_smallk_f32: null or misaligned pointer");
+    int R = 4;                                           // measured: 2 -> 25.6 us, 4 -> 23.0, 8 -> 26.4 (15 777 x 24 -> 512)
+    if (const char* e = getenv("HD_SMALLK_R")) R = atoi(e);
+#define HD_SK(R_)                                                                                              \
+    {                                                                                                          \
+        int64_t blocks = (rows + 4 * R_ - 1) / (4 * R_);                                                       \
+        blocks = blocks < 4096 ? blocks : 4096;                                                                \
+        hb_linear_smallk<R_><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)st>>>(                       \
+            (const float*)x, (const float*)Wt, (float*)out, rows, (int)d_in, (int)d_out, mk(c), flags);        \
+    }
+    if (R == 2) HD_SK(2) else if (R == 8) HD_SK(8) else HD_SK(4)
+#undef HD_SK
+    return check_launch("hd_hb_linear_smallk_f32");
+}

@@ -46,7 +46,15 @@ class Hyperboloid(Manifold):
             return hag.HypLinearFn.apply(x2, m, "hb", ops.curv(c), _flags)
         if m.dtype != x2.dtype:
             m = m.to(x2.dtype)
+        K, N = x2.shape[1], m.shape[0]
         m = ops.match_padded(x2, m)
+        if x2.dtype == torch.float32 and m.dtype == torch.float32 and K <= 64 and N <= 512 and N % 4 == 0 and x2.shape[0] > 0:
+            # narrow input (first layer of the graph-set configs): logmap0, the fp32 contraction and the
+            # row tail in one launch -- nothing between x and the result touches memory
+            out = torch.empty(x2.shape[0], N, dtype=torch.float32, device=x2.device)
+            ops._lib.call("hd_hb_linear_smallk_f32", ops._p(x2), ops._p(ops.transposed_cached(m)), ops._p(out),
+                          x2.shape[0], K, N, ops.curv(c), _flags, ops._stream())
+            return out
         if ops.use_f16x2(x2, m):
             # logmap0 writes the f16x2 limb image of the GEMM operand directly (one pass over x)
             mu, _ = ops.gemm_limbs(ops.row_pack(x2, 1, c), ops.weight_limbs(m, "f16x2")[0])

@@ -191,6 +191,21 @@ def pad_k_cached(t, k_pad):
     return out
 
 
+_wt_cache = {}
+
+
+def transposed_cached(w):
+    """w^T as a contiguous tensor, rebuilt when the parameter changes (keyed like pad_k_cached)."""
+    hit = _wt_cache.get(id(w))
+    if hit is not None and hit[0]() is w and hit[1] == (w._version, w.data_ptr()):
+        return hit[2]
+    out = w.detach().t().contiguous()
+    if len(_wt_cache) > 64:
+        _wt_cache.clear()
+    _wt_cache[id(w)] = (weakref.ref(w), (w._version, w.data_ptr()), out)
+    return out
+
+
 def match_padded(x2, m):
     """A weight whose input carries zero pad columns (models/encoders._lift pads the features to
     16-byte rows once): pad the weight's K to the same width (cached per parameter version)."""

@@ -101,6 +101,14 @@ HD_DECL2(hd_hb_linear_epilogue, const void* mu, void* out, int64_t rows, int64_t
 HD_DECL2(hd_hb_hyp_act, const void* x, void* out, int64_t rows, int64_t dim, hd_curv c_in, hd_curv c_out,
          int act, void* stream)
 
+/* HypLinear on the hyperboloid with a narrow input, ONE launch (layers/hyp_layers.py:98-103,
+ * manifolds/hyperboloid.py:103-123): out = tail(logmap0(x, c) @ W^T) with tail = expmap0 (flags&1: proj,
+ * flags&2: logmap0) as in hd_hb_linear_epilogue.  x (rows, d_in) fp32 contiguous, Wt = W^T (d_in, d_out) fp32
+ * contiguous, 16-byte aligned; d_in <= 64, d_out <= 512 and a multiple of 4.  The contraction is an fp32 fma
+ * chain over k (exact fp32, no limbs). */
+int hd_hb_linear_smallk_f32(const void* x, const void* Wt, void* out, int64_t rows, int64_t d_in, int64_t d_out,
+                            hd_curv c, int flags, void* stream);
+
 /* ---- backward of the row maps (autograd of the encoder as lp_train.py:66-82 trains it) ------
  * Each is the vector-Jacobian product of one forward entry point above: `saved` row + incoming
  * gradient -> outgoing gradient, clamps and torch.where branches differentiated the way torch
