@@ -1,10 +1,15 @@
 """Hyperboloid on HIP kernels -- drop-in for the reference's manifolds/hyperboloid.py.
 Column 0 is the time coordinate; like the reference, proj/expmap0/logmap0 take 2-D
 inputs (hyperboloid.py:47,95,108 index dim=1)."""
+import os
+
 import torch
 
 from .. import ops
 from .base import Manifold
+
+
+_NO_SMALLK = bool(os.environ.get("HD_NO_SMALLK"))      # debugging knob: force the wide HypLinear path
 
 
 class Hyperboloid(Manifold):
@@ -48,7 +53,8 @@ class Hyperboloid(Manifold):
             m = m.to(x2.dtype)
         K, N = x2.shape[1], m.shape[0]
         m = ops.match_padded(x2, m)
-        if x2.dtype == torch.float32 and m.dtype == torch.float32 and K <= 64 and N <= 512 and N % 4 == 0 and x2.shape[0] > 0:
+        if (x2.dtype == torch.float32 and m.dtype == torch.float32 and K <= 64 and N <= 512 and N % 4 == 0
+                and x2.shape[0] > 0 and not _NO_SMALLK):
             # narrow input (first layer of the graph-set configs): logmap0, the fp32 contraction and the
             # row tail in one launch -- nothing between x and the result touches memory
             out = torch.empty(x2.shape[0], N, dtype=torch.float32, device=x2.device)
