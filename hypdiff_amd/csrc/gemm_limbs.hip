@@ -175,8 +175,8 @@ __global__ __launch_bounds__(256) void limb_pack(const float* __restrict__ in, i
     }
 }
 
-// Row producers that write the f16x2 image of a GEMM operand directly, in one pass over the rows: one
-// wavefront per row, a lane owns the 8-column chunks lane, lane + 64, ...; the row maximum (and the
+// Row producers that write the f16x2 image of a GEMM operand directly, in one pass over the rows: a
+// wavefront takes a row at a time, a lane owns the 8-column chunks lane, lane + 64, ...; the row maximum (and the
 // row norm, where the map needs one) is a wavefront reduction, so the row is read once and no fp32
 // copy of the operand is made.
 //   PACK_MLP     cat(x.float(), t[:,None])            models/direction_diffusion.py:57-58
@@ -189,8 +189,16 @@ __global__ __launch_bounds__(256) void row_pack_f16x2(const TX* __restrict__ x, 
                                                       float t_scalar, int rows, int dim, int nslab, Curv cv,
                                                       uint4* __restrict__ out, int* __restrict__ ex,
                                                       unsigned* __restrict__ amax, float* __restrict__ norms) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= rows) return;
+    // A workgroup owns 16 consecutive rows (4 per wavefront, one after the other).  The limbs go to LDS
+    // first ([limb][chunk][row], 17-chunk pitch: conflict-free both ways) and leave as 256-byte runs -- in
+    // the image the 16 rows of one (limb, chunk) are contiguous, whereas a row's own chunks lie 2 KiB apart.
+    extern __shared__ uint4 stage[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunk = nslab * 4;
+    for (int it = 0; it < 4; ++it) {
+    const int r16 = wave * 4 + it;
+    const int row = blockIdx.x * 16 + r16;
+    if (row >= rows) continue;
     constexpr int V = 16 / sizeof(TX);
     using VT = typename VecOf<TX>::type;
     const TX* xr = x + (int64_t)row * dim;
@@ -198,7 +206,6 @@ __global__ __launch_bounds__(256) void row_pack_f16x2(const TX* __restrict__ x, 
     float tv = 0.f;
     if constexpr (MODE == PACK_MLP)
         tv = t_kind == 0 ? (float)((const int64_t*)t)[row] : (t_kind == 1 ? ((const float*)t)[row] : t_scalar);
-    const int nchunk = nslab * 4;
     float v[kPackChunks][8];
 #pragma unroll
     for (int q = 0; q < kPackChunks; ++q) {
@@ -255,7 +262,6 @@ __global__ __launch_bounds__(256) void row_pack_f16x2(const TX* __restrict__ x, 
         amax[row] = __float_as_uint(m);
         ex[row] = e_row;
     }
-    uint4* orow = out + (int64_t)(row >> 7) * nslab * kTileOf<true> + (row & 127);
 #pragma unroll
     for (int q = 0; q < kPackChunks; ++q) {
         const int ch = lane + 64 * q;
@@ -263,9 +269,18 @@ __global__ __launch_bounds__(256) void row_pack_f16x2(const TX* __restrict__ x, 
         uint2 h0, l0, h1, l1;
         split4_f16(make_float4(ldexpf(v[q][0], e_row), ldexpf(v[q][1], e_row), ldexpf(v[q][2], e_row), ldexpf(v[q][3], e_row)), h0, l0);
         split4_f16(make_float4(ldexpf(v[q][4], e_row), ldexpf(v[q][5], e_row), ldexpf(v[q][6], e_row), ldexpf(v[q][7], e_row)), h1, l1);
-        uint4* o = orow + (int64_t)(ch >> 2) * kTileOf<true> + (ch & 3) * 128;
-        o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-        o[4 * 128] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        stage[ch * 17 + r16] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        stage[(nchunk + ch) * 17 + r16] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+    }
+    __syncthreads();
+    const int row16 = threadIdx.x & 15;
+    const int64_t grow = (int64_t)blockIdx.x * 16 + row16;
+    if (grow >= rows) return;
+    uint4* obase = out + (grow >> 7) * nslab * kTileOf<true> + (grow & 127);
+    for (int p = threadIdx.x >> 4; p < 2 * nchunk; p += 16) {
+        const int l = p >= nchunk, ch = p - l * nchunk;
+        obase[(int64_t)(ch >> 2) * kTileOf<true> + l * 4 * 128 + (ch & 3) * 128] = stage[p * 17 + row16];
     }
 }
 
@@ -669,6 +684,15 @@ extern "C" int hd_limb_pack_f16x2_f32(const void* in, int64_t ld, int64_t rows, 
     return pack_impl<true>("hd_limb_pack_f16x2_f32", in, ld, rows, cols, out, ex, amax, st);
 }
 
+// rows wider than ~950 columns stage more than the 64 KiB of LDS a workgroup gets by default
+template <typename K> static int allow_lds(K kernel, size_t bytes, const char* who) {
+    if (bytes <= 64 * 1024) return HD_OK;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute(%zu B of LDS): %s", who, bytes, hipGetErrorString(e)); return HD_EHIP; }
+    return HD_OK;
+}
+
 extern "C" int hd_mlp_pack_input_f16x2(const void* x, int x_dtype, const void* t, int t_kind, double t_scalar,
                                        void* out, void* ex, void* amax, int64_t rows, int64_t dim, void* st) {
     HD_REQUIRE(rows >= 0 && dim >= 1 && dim + 1 <= 64 * 8 * kPackChunks, "hd_mlp_pack_input_f16x2: dim out of range (<= %d)",
@@ -678,13 +702,16 @@ extern "C" int hd_mlp_pack_input_f16x2(const void* x, int x_dtype, const void* t
                "hd_mlp_pack_input_f16x2: bad argument");
     HD_REQUIRE(rows < (1LL << 31), "hd_mlp_pack_input_f16x2: size exceeds int32");
     const int nslab = (int)((dim + 1 + 31) / 32);
-    const dim3 grid((unsigned)((rows + 3) / 4));
+    const dim3 grid((unsigned)((rows + 15) / 16));
+    const size_t lds = (size_t)2 * nslab * 4 * 17 * sizeof(uint4);
+    if (int rc = x_dtype ? allow_lds(row_pack_f16x2<PACK_MLP, double>, lds, "hd_mlp_pack_input_f16x2")
+                         : allow_lds(row_pack_f16x2<PACK_MLP, float>, lds, "hd_mlp_pack_input_f16x2")) return rc;
     if (x_dtype)
-        row_pack_f16x2<PACK_MLP, double><<<grid, 256, 0, (hipStream_t)st>>>(
+        row_pack_f16x2<PACK_MLP, double><<<grid, 256, lds, (hipStream_t)st>>>(
             (const double*)x, t, t_kind, (float)t_scalar, (int)rows, (int)dim, nslab, Curv{}, (uint4*)out, (int*)ex,
             (unsigned*)amax, nullptr);
     else
-        row_pack_f16x2<PACK_MLP, float><<<grid, 256, 0, (hipStream_t)st>>>(
+        row_pack_f16x2<PACK_MLP, float><<<grid, 256, lds, (hipStream_t)st>>>(
             (const float*)x, t, t_kind, (float)t_scalar, (int)rows, (int)dim, nslab, Curv{}, (uint4*)out, (int*)ex,
             (unsigned*)amax, nullptr);
     return check_launch("hd_mlp_pack_input_f16x2");
@@ -700,13 +727,16 @@ extern "C" int hd_row_pack_f16x2_f32(const void* x, int mode, hd_curv c, void* o
                "hd_row_pack_f16x2_f32: null or misaligned pointer");
     HD_REQUIRE(rows < (1LL << 31), "hd_row_pack_f16x2_f32: size exceeds int32");
     const int nslab = (int)((dim + 31) / 32);
-    const dim3 grid((unsigned)((rows + 3) / 4));
+    const dim3 grid((unsigned)((rows + 15) / 16));
+    const size_t lds = (size_t)2 * nslab * 4 * 17 * sizeof(uint4);
     const Curv cv{c.c, c.sqrt_c, c.K, c.sqrt_K};
+    if (int rc = mode == PACK_HB_LOG0 ? allow_lds(row_pack_f16x2<PACK_HB_LOG0, float>, lds, "hd_row_pack_f16x2_f32")
+                                      : allow_lds(row_pack_f16x2<PACK_NORM, float>, lds, "hd_row_pack_f16x2_f32")) return rc;
     if (mode == PACK_HB_LOG0)
-        row_pack_f16x2<PACK_HB_LOG0, float><<<grid, 256, 0, (hipStream_t)st>>>(
+        row_pack_f16x2<PACK_HB_LOG0, float><<<grid, 256, lds, (hipStream_t)st>>>(
             (const float*)x, nullptr, 2, 0.f, (int)rows, (int)dim, nslab, cv, (uint4*)out, (int*)ex, (unsigned*)amax, nullptr);
     else
-        row_pack_f16x2<PACK_NORM, float><<<grid, 256, 0, (hipStream_t)st>>>(
+        row_pack_f16x2<PACK_NORM, float><<<grid, 256, lds, (hipStream_t)st>>>(
             (const float*)x, nullptr, 2, 0.f, (int)rows, (int)dim, nslab, cv, (uint4*)out, (int*)ex, (unsigned*)amax,
             (float*)norms);
     return check_launch("hd_row_pack_f16x2_f32");
