@@ -59,6 +59,7 @@ SIGNATURES = {
     "hd_hb_edge_decode*": [P, P, I64, P, I64, I64, HdCurv, c_int, c_double, c_double, P],
     "hd_pb_edge_decode_bwd*": [P, P, I64, P, P, I64, I64, HdCurv, c_int, c_double, c_double, P],
     "hd_hb_edge_decode_bwd*": [P, P, I64, P, P, I64, I64, HdCurv, c_int, c_double, c_double, P],
+    "hd_hb_linear_tail_rows_f32": [P, P, I64, I64, HdCurv, c_int, P],
     "hd_hb_linear_smallk_f32": [P, P, P, I64, I64, I64, HdCurv, c_int, P],
     "hd_csr_from_coo": [P, P, I64, I64, I64, P, P, P, P],
     "hd_adj_count": [P, P, I64, P, P, P],

@@ -189,89 +189,107 @@ __global__ __launch_bounds__(256) void row_pack_f16x2(const TX* __restrict__ x, 
                                                       float t_scalar, int rows, int dim, int nslab, Curv cv,
                                                       uint4* __restrict__ out, int* __restrict__ ex,
                                                       unsigned* __restrict__ amax, float* __restrict__ norms) {
-    // A workgroup owns 16 consecutive rows (4 per wavefront, one after the other).  The limbs go to LDS
-    // first ([limb][chunk][row], 17-chunk pitch: conflict-free both ways) and leave as 256-byte runs -- in
-    // the image the 16 rows of one (limb, chunk) are contiguous, whereas a row's own chunks lie 2 KiB apart.
+    // A workgroup owns 16 consecutive rows, 4 per wavefront.  The limbs go to LDS first ([limb][chunk][row],
+    // 17-chunk pitch: conflict-free both ways) and leave as 256-byte runs -- in the image the 16 rows of one
+    // (limb, chunk) are contiguous, whereas a row's own chunks lie 2 KiB apart.  A wavefront loads its 4 rows
+    // together and evaluates logmap0's scalar chain (fp32 arcosh: wavefront-uniform in a row-at-a-time
+    // kernel, i.e. computed 64 times over) once for all of them, row i in lane i.
     extern __shared__ uint4 stage[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nchunk = nslab * 4;
-    for (int it = 0; it < 4; ++it) {
-    const int r16 = wave * 4 + it;
-    const int row = blockIdx.x * 16 + r16;
-    if (row >= rows) continue;
+    constexpr int RW = 4;
     constexpr int V = 16 / sizeof(TX);
     using VT = typename VecOf<TX>::type;
-    const TX* xr = x + (int64_t)row * dim;
-    const bool vec_ok = (reinterpret_cast<uintptr_t>(xr) & 15) == 0;
-    float tv = 0.f;
-    if constexpr (MODE == PACK_MLP)
-        tv = t_kind == 0 ? (float)((const int64_t*)t)[row] : (t_kind == 1 ? ((const float*)t)[row] : t_scalar);
-    float v[kPackChunks][8];
+    float v[RW][kPackChunks][8];
+    float ss_l = 0.f, x0_l = 0.f;
 #pragma unroll
-    for (int q = 0; q < kPackChunks; ++q) {
-        const int c0 = (lane + 64 * q) * 8;
-        if (c0 + 8 <= dim && vec_ok) {
+    for (int it = 0; it < RW; ++it) {
+        const int row_raw = blockIdx.x * 16 + wave * RW + it;
+        const int row = row_raw < rows ? row_raw : rows - 1;
+        const TX* xr = x + (int64_t)row * dim;
+        const bool vec_ok = (reinterpret_cast<uintptr_t>(xr) & 15) == 0;
+        float tv = 0.f;
+        if constexpr (MODE == PACK_MLP)
+            tv = t_kind == 0 ? (float)((const int64_t*)t)[row] : (t_kind == 1 ? ((const float*)t)[row] : t_scalar);
 #pragma unroll
-            for (int g = 0; g < 8 / V; ++g) {
-                const VT pk = *reinterpret_cast<const VT*>(xr + c0 + g * V);
-                const TX* pe = reinterpret_cast<const TX*>(&pk);
+        for (int q = 0; q < kPackChunks; ++q) {
+            const int c0 = (lane + 64 * q) * 8;
+            if (c0 + 8 <= dim && vec_ok) {
 #pragma unroll
-                for (int e = 0; e < V; ++e) v[q][g * V + e] = (float)pe[e];
-            }
-        } else {
+                for (int g = 0; g < 8 / V; ++g) {
+                    const VT pk = *reinterpret_cast<const VT*>(xr + c0 + g * V);
+                    const TX* pe = reinterpret_cast<const TX*>(&pk);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int c = c0 + e;
-                v[q][e] = c < dim ? (float)xr[c] : (MODE == PACK_MLP && c == dim ? tv : 0.f);
+                    for (int e = 0; e < V; ++e) v[it][q][g * V + e] = (float)pe[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = c0 + e;
+                    v[it][q][e] = c < dim ? (float)xr[c] : (MODE == PACK_MLP && c == dim ? tv : 0.f);
+                }
             }
         }
-    }
-    if constexpr (MODE != PACK_MLP) {
-        float ss = 0.f;
-#pragma unroll
-        for (int q = 0; q < kPackChunks; ++q)
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (!(MODE == PACK_HB_LOG0 && q == 0 && e == 0 && lane == 0)) ss += v[q][e] * v[q][e];
-#pragma unroll
-        for (int off = 32; off; off >>= 1) ss += __shfl_xor(ss, off);
-        if constexpr (MODE == PACK_NORM) {
-            if (lane == 0) norms[row] = sqrtf(ss);
-        } else {
-            const float x0 = __shfl(v[0][0], 0);
-            const float sK = (float)cv.sK;
-            const float n = clamp_min(hd_sqrt(ss), (float)kMinNorm);
-            const float theta = clamp_min(x0 / sK, (float)(1.0 + Lim<float>::hb_eps));
-            const float f = sK * arcosh_ref(theta) / n;
+        if constexpr (MODE != PACK_MLP) {
+            float ss = 0.f;
 #pragma unroll
             for (int q = 0; q < kPackChunks; ++q)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[q][e] *= f;
-            if (lane == 0) v[0][0] = 0.f;
+                for (int e = 0; e < 8; ++e)
+                    if (!(MODE == PACK_HB_LOG0 && q == 0 && e == 0 && lane == 0)) ss += v[it][q][e] * v[it][q][e];
+#pragma unroll
+            for (int off = 32; off; off >>= 1) ss += __shfl_xor(ss, off);
+            if constexpr (MODE == PACK_NORM) {
+                if (lane == 0 && row_raw < rows) norms[row] = sqrtf(ss);
+            } else {
+                const float x0 = __shfl(v[it][0][0], 0);
+                if (lane == it) { ss_l = ss; x0_l = x0; }
+            }
         }
     }
-    float m = 0.f;
-#pragma unroll
-    for (int q = 0; q < kPackChunks; ++q)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[q][e]));
-#pragma unroll
-    for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    const int e_row = exp_for(m, 15);
-    if (lane == 0) {
-        amax[row] = __float_as_uint(m);
-        ex[row] = e_row;
+    float f_l = 1.f;
+    if constexpr (MODE == PACK_HB_LOG0) {                       // hyperboloid.py:103-113, the 4 rows at once
+        const float sK = (float)cv.sK;
+        const float n = clamp_min(hd_sqrt(ss_l), (float)kMinNorm);
+        const float theta = clamp_min(x0_l / sK, (float)(1.0 + Lim<float>::hb_eps));
+        f_l = sK * arcosh_ref(theta) / n;
     }
 #pragma unroll
-    for (int q = 0; q < kPackChunks; ++q) {
-        const int ch = lane + 64 * q;
-        if (ch >= nchunk) continue;
-        uint2 h0, l0, h1, l1;
-        split4_f16(make_float4(ldexpf(v[q][0], e_row), ldexpf(v[q][1], e_row), ldexpf(v[q][2], e_row), ldexpf(v[q][3], e_row)), h0, l0);
-        split4_f16(make_float4(ldexpf(v[q][4], e_row), ldexpf(v[q][5], e_row), ldexpf(v[q][6], e_row), ldexpf(v[q][7], e_row)), h1, l1);
-        stage[ch * 17 + r16] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-        stage[(nchunk + ch) * 17 + r16] = make_uint4(l0.x, l0.y, l1.x, l1.y);
-    }
+    for (int it = 0; it < RW; ++it) {
+        const int r16 = wave * RW + it;
+        const int row = blockIdx.x * 16 + r16;
+        if constexpr (MODE == PACK_HB_LOG0) {
+            const float f = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f_l), it));
+#pragma unroll
+            for (int q = 0; q < kPackChunks; ++q)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[it][q][e] *= f;
+            if (lane == 0) v[it][0][0] = 0.f;
+        }
+        float m = 0.f;
+#pragma unroll
+        for (int q = 0; q < kPackChunks; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[it][q][e]));
+#pragma unroll
+        for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        const int e_row = exp_for(m, 15);
+        if (lane == 0 && row < rows) {
+            amax[row] = __float_as_uint(m);
+            ex[row] = e_row;
+        }
+#pragma unroll
+        for (int q = 0; q < kPackChunks; ++q) {
+            const int ch = lane + 64 * q;
+            if (ch >= nchunk) continue;
+            uint2 h0, l0, h1, l1;
+            split4_f16(make_float4(ldexpf(v[it][q][0], e_row), ldexpf(v[it][q][1], e_row), ldexpf(v[it][q][2], e_row),
+                                   ldexpf(v[it][q][3], e_row)), h0, l0);
+            split4_f16(make_float4(ldexpf(v[it][q][4], e_row), ldexpf(v[it][q][5], e_row), ldexpf(v[it][q][6], e_row),
+                                   ldexpf(v[it][q][7], e_row)), h1, l1);
+            stage[ch * 17 + r16] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            stage[(nchunk + ch) * 17 + r16] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        }
     }
     __syncthreads();
     const int row16 = threadIdx.x & 15;

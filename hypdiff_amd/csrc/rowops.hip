@@ -307,7 +307,50 @@ __global__ __launch_bounds__(256) void hb_linear_smallk(const float* __restrict_
     }
 }
 
+// hd_hb_linear_epilogue for fp32 rows of up to 512 columns: four rows per wavefront, scalar chain once
+template <int R>
+__global__ __launch_bounds__(256) void hb_linear_tail_rows(const float* __restrict__ mu, float* __restrict__ out,
+                                                           int64_t n, int d, Curv cv, int flags) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    using TL = Tile<float, 64, 4, 8>;
+    for (int64_t base = ((int64_t)blockIdx.x * 4 + wave) * R; base < n; base += (int64_t)gridDim.x * 4 * R) {
+        TL r[R];
+        float s2_l = 0.f;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            r[i].init(d);
+            r[i].load(mu + (base + i < n ? base + i : n - 1) * d);
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const float s2 = r[i].sumsq(1);
+            if (lane == i) s2_l = s2;
+        }
+        float f_l, t0_l;
+        hb_linear_tail_scalars(s2_l, flags, cv, f_l, t0_l);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            r[i].scale(lane_get(f_l, i), 1);
+            r[i].set_first(lane_get(t0_l, i));
+            if (base + i < n) r[i].store(out + (base + i) * d);
+        }
+    }
+}
+
 }  // namespace
+
+// fp32 rows short enough for one 64-lane tile: the four-rows-per-wavefront kernel above
+extern "C" int hd_hb_linear_tail_rows_f32(const void* mu, void* out, int64_t n, int64_t d, hd_curv c, int flags,
+                                          void* st) {
+    HD_REQUIRE(n >= 0 && d >= 4 && d <= 512 && d % 4 == 0, "hd_hb_linear_tail_rows_f32: dim must be a multiple of 4, <= 512");
+    if (n == 0) return HD_OK;
+    HD_REQUIRE(mu && out && is_aligned16(mu) && is_aligned16(out), "hd_hb_linear_tail_rows_f32: null or misaligned pointer");
+    int64_t blocks = (n + 15) / 16;
+    blocks = blocks < 4096 ? blocks : 4096;
+    hb_linear_tail_rows<4><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)st>>>((const float*)mu, (float*)out, n,
+                                                                                      (int)d, mk(c), flags);
+    return check_launch("hd_hb_linear_tail_rows_f32");
+}
 
 extern "C" int hd_hb_linear_smallk_f32(const void* x, const void* Wt, void* out, int64_t rows, int64_t d_in,
                                        int64_t d_out, hd_curv c, int flags, void* st) {

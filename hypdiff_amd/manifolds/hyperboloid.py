@@ -67,8 +67,12 @@ class Hyperboloid(Manifold):
         else:
             mu = ops.gemm(ops.map1("hd_hb_logmap0", x2, c), m)
         out = torch.empty_like(mu)
-        ops._lib.call("hd_hb_linear_epilogue" + ops._sfx(mu), ops._p(mu), ops._p(out), mu.shape[0], mu.shape[1],
-                      ops.curv(c), _flags, ops._stream())
+        if mu.dtype == torch.float32 and mu.shape[1] <= 512 and mu.shape[1] % 4 == 0 and mu.is_contiguous():
+            ops._lib.call("hd_hb_linear_tail_rows_f32", ops._p(mu), ops._p(out), mu.shape[0], mu.shape[1], ops.curv(c),
+                          _flags, ops._stream())
+        else:
+            ops._lib.call("hd_hb_linear_epilogue" + ops._sfx(mu), ops._p(mu), ops._p(out), mu.shape[0], mu.shape[1],
+                          ops.curv(c), _flags, ops._stream())
         return out
 
     # ---- bias path of HypLinear (use_bias=1, not the default): tensor algebra over the

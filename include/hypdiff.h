@@ -106,6 +106,10 @@ HD_DECL2(hd_hb_hyp_act, const void* x, void* out, int64_t rows, int64_t dim, hd_
  * flags&2: logmap0) as in hd_hb_linear_epilogue.  x (rows, d_in) fp32 contiguous, Wt = W^T (d_in, d_out) fp32
  * contiguous, 16-byte aligned; d_in <= 64, d_out <= 512 and a multiple of 4.  The contraction is an fp32 fma
  * chain over k (exact fp32, no limbs). */
+/* hd_hb_linear_epilogue_f32 for rows of up to 512 columns (a multiple of 4; 16-byte aligned): four rows per
+ * wavefront, the row's scalar chain evaluated once per wavefront instead of once per lane. */
+int hd_hb_linear_tail_rows_f32(const void* mu, void* out, int64_t rows, int64_t dim, hd_curv c, int flags,
+                               void* stream);
 int hd_hb_linear_smallk_f32(const void* x, const void* Wt, void* out, int64_t rows, int64_t d_in, int64_t d_out,
                             hd_curv c, int flags, void* stream);
 
