@@ -202,8 +202,8 @@ HD_EPI(double, f64)
 // HGCN layer of the graph-set configs: 21 features -> 512), so the three launches of the wide path (operand
 // producer, matrix-core GEMM, row tail) spend their time on launch ramps and on writing / re-reading mu.
 // Here a wavefront owns R rows: it reads x, takes logmap0, accumulates mu = u W^T as an fp32 fma chain over
-// k against W^T ((d_in, d_out) row-major, a few tens of KB: every wavefront streams it from L2 with 16-byte
-// loads, each reused for the R rows), applies the row tail to the accumulators (they already sit in the
+// k against W^T ((d_in, d_out) row-major, a few tens of KB: copied to LDS once per 16-wavefront workgroup, or
+// streamed from L2 when it does not fit; 16-byte reads, each reused for the R rows), applies the row tail to the accumulators (they already sit in the
 // row-tile layout of the row kernels) and writes the result: x is read once, the output written once,
 // nothing in between touches memory.
 namespace {
@@ -238,15 +238,23 @@ __device__ __forceinline__ float lane_get(float v, int l) {
 // transcendental issues per row) are wavefront-uniform in the row kernels, i.e. computed 64 times over.
 // Here a wavefront owns R rows and evaluates each chain ONCE for all of them, row r in lane r, then hands
 // the factors back with v_readlane: the kernel is bound by exactly this VALU work otherwise.
-template <int R>
-__global__ __launch_bounds__(256) void hb_linear_smallk(const float* __restrict__ x, const float* __restrict__ Wt,
+template <int R, int WAVES, bool LDSW>
+__global__ __launch_bounds__(WAVES * 64) void hb_linear_smallk(const float* __restrict__ x, const float* __restrict__ Wt_g,
                                                         float* __restrict__ out, int64_t n, int K, int N,
                                                         Curv cv, int flags) {
+    extern __shared__ float4 Ws4[];                          // LDSW: W^T copied once per workgroup (K * N floats)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* Wt = Wt_g;
+    if constexpr (LDSW) {
+        const float4* src = reinterpret_cast<const float4*>(Wt_g);
+        for (int i = tid; i < K * N / 4; i += WAVES * 64) Ws4[i] = src[i];
+        __syncthreads();
+        Wt = reinterpret_cast<const float*>(Ws4);
+    }
     using TL = Tile<float, 64, 4, 8>;
     const float sK = (float)cv.sK;
     const int c0 = 4 * lane, c1 = 256 + 4 * lane;
-    for (int64_t base = ((int64_t)blockIdx.x * 4 + wave) * R; base < n; base += (int64_t)gridDim.x * 4 * R) {
+    for (int64_t base = ((int64_t)blockIdx.x * WAVES + wave) * R; base < n; base += (int64_t)gridDim.x * WAVES * R) {
         float xv[R], u[R];
         float ss_l = 0.f, x0_l = 0.f;                        // lane r: row r's spatial |x|^2 and time coordinate
 #pragma unroll
@@ -364,10 +372,20 @@ extern "C" int hd_hb_linear_smallk_f32(const void* x, const void* Wt, void* out,
     {                                                                                                          \
         int64_t blocks = (rows + 4 * R_ - 1) / (4 * R_);                                                       \
         blocks = blocks < 4096 ? blocks : 4096;                                                                \
-        hb_linear_smallk<R_><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)st>>>(                       \
+        hb_linear_smallk<R_, 4, false><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)st>>>(             \
             (const float*)x, (const float*)Wt, (float*)out, rows, (int)d_in, (int)d_out, mk(c), flags);        \
     }
-    if (R == 2) HD_SK(2) else if (R == 8) HD_SK(8) else HD_SK(4)
+    int lds_mode = 2;                                    // measured in the bench step: 0 (W^T from L2) 33 us, 1-3: 21 us
+    if (const char* e = getenv("HD_SMALLK_LDS")) lds_mode = atoi(e);
+    const size_t wbytes = (size_t)d_in * d_out * sizeof(float);
+    if (lds_mode && wbytes <= 64 * 1024) {
+        // W^T in LDS, 16 wavefronts per workgroup: lds_mode = workgroups per CU (256 CUs assumed for the grid)
+        int64_t blocks = (rows + 16 * 4 - 1) / (16 * 4);
+        const int64_t cap = 256LL * lds_mode;
+        blocks = blocks < cap ? blocks : cap;
+        hb_linear_smallk<4, 16, true><<<dim3((unsigned)blocks), dim3(1024), wbytes, (hipStream_t)st>>>(
+            (const float*)x, (const float*)Wt, (float*)out, rows, (int)d_in, (int)d_out, mk(c), flags);
+    } else if (R == 2) HD_SK(2) else if (R == 8) HD_SK(8) else HD_SK(4)
 #undef HD_SK
     return check_launch("hd_hb_linear_smallk_f32");
 }

@@ -231,6 +231,45 @@ def test_f16x2_edge_cases():
     assert np.array_equal(H(t._indices()), np.array([[0, 1, 2], [0, 1, 2]])) and np.array_equal(H(t._values()), np.ones(3, np.float32))
 
 
+def test_hb_linear_narrow_and_tail_kernels():
+    """hd_hb_linear_smallk_f32 (one-launch HypLinear for d_in <= 64; W^T in LDS or, when it does not fit, from L2)
+    and hd_hb_linear_tail_rows_f32 against the composition they replace -- hd_hb_logmap0 -> exact fp32 GEMM ->
+    hd_hb_linear_epilogue -- and against the oracle's mobius_matvec chain."""
+    from hypdiff_amd import ops
+    from oracle import manifolds as om
+    rs = np.random.RandomState(21)
+    for (n, K, N) in [(777, 21, 512), (300, 64, 512), (130, 5, 8), (1, 24, 64), (515, 32, 256)]:
+        u = rs.standard_normal((n, K)).astype(np.float32) * 0.5
+        u[:, 0] = 0.0
+        if n > 3:
+            u[3, 1:] = 0.0                                                         # a row at the origin
+        x = ops.map1("hd_hb_expmap0_proj", G(u), 1.0)
+        w = G((rs.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+        for flags in (0, 1, 3):
+            got = torch.empty(n, N, device="cuda")
+            ops._lib.call("hd_hb_linear_smallk_f32", ops._p(x), ops._p(w.t().contiguous()), ops._p(got), n, K, N,
+                          ops.curv(1.0), flags, ops._stream())
+            old, ops.GEMM_MODE = ops.GEMM_MODE, "exact"
+            try:
+                kp = (K + 3) // 4 * 4
+                mu = ops.gemm(ops._pad_k(ops.map1("hd_hb_logmap0", x, 1.0), kp), ops._pad_k(w, kp))
+            finally:
+                ops.GEMM_MODE = old
+            want = torch.empty_like(mu)
+            ops._lib.call("hd_hb_linear_epilogue_f32", ops._p(mu), ops._p(want), n, N, ops.curv(1.0), flags, ops._stream())
+            assert_close(H(got), H(want), what=f"smallk {(n, K, N, flags)}", atol_scale=2e-6)
+            fast = torch.empty_like(mu)
+            ops._lib.call("hd_hb_linear_tail_rows_f32", ops._p(mu), ops._p(fast), n, N, ops.curv(1.0), flags, ops._stream())
+            assert_close(H(fast), H(want), what=f"tail_rows {(n, N, flags)}", atol_scale=2e-6)
+        ref = om.hb_proj(om.hb_mobius_matvec(torch.from_numpy(H(w)), torch.from_numpy(H(x)), 1.0), 1.0) \
+            if True else None
+        if ref is not None:
+            got = torch.empty(n, N, device="cuda")
+            ops._lib.call("hd_hb_linear_smallk_f32", ops._p(x), ops._p(w.t().contiguous()), ops._p(got), n, K, N,
+                          ops.curv(1.0), 1, ops._stream())
+            assert_close(H(got), ref.numpy(), what=f"smallk vs oracle {(n, K, N)}", atol_scale=2e-6)
+
+
 def test_csr_unsorted_empty_rows_and_bounds():
     from hypdiff_amd import ops
     rs = np.random.RandomState(3)
