@@ -53,7 +53,9 @@ class Hyperboloid(Manifold):
             m = m.to(x2.dtype)
         K, N = x2.shape[1], m.shape[0]
         m = ops.match_padded(x2, m)
-        if (x2.dtype == torch.float32 and m.dtype == torch.float32 and K <= 64 and N <= 512 and N % 4 == 0
+        # (the two 64-lane-per-row kernels below pay off from ~128 / 256 columns; narrower rows keep the
+        # generic row kernels, which put 4 or 16 lanes on a row)
+        if (x2.dtype == torch.float32 and m.dtype == torch.float32 and K <= 64 and 128 <= N <= 512 and N % 4 == 0
                 and x2.shape[0] > 0 and not _NO_SMALLK):
             # narrow input (first layer of the graph-set configs): logmap0, the fp32 contraction and the
             # row tail in one launch -- nothing between x and the result touches memory
@@ -67,7 +69,7 @@ class Hyperboloid(Manifold):
         else:
             mu = ops.gemm(ops.map1("hd_hb_logmap0", x2, c), m)
         out = torch.empty_like(mu)
-        if mu.dtype == torch.float32 and mu.shape[1] <= 512 and mu.shape[1] % 4 == 0 and mu.is_contiguous():
+        if mu.dtype == torch.float32 and 256 <= mu.shape[1] <= 512 and mu.shape[1] % 4 == 0 and mu.is_contiguous():
             ops._lib.call("hd_hb_linear_tail_rows_f32", ops._p(mu), ops._p(out), mu.shape[0], mu.shape[1], ops.curv(c),
                           _flags, ops._stream())
         else:

@@ -106,6 +106,31 @@ def main():
                               ops._p(out), n, d, 1.0, 500.0, 1.0, ops._stream())
             report("p_sample_update(f64 x_t)", sh, n * d * (8 + 4 + 4 + 8) + 4 * n, timeit(upd, a.iters))
             report("moments+standardize(f32)", sh, 3 * B, timeit(lambda: dm.normalization(x), a.iters))
+            # f16x2 operand producers and the HypLinear tail / narrow-input kernels (csrc/gemm_limbs.hip, rowops.hip)
+            if d <= 1535:
+                img = ops.limb_empty(n, d + 1, dev, "f16x2", zero_amax=False)
+                nsl = (d + 1 + 31) // 32 * 32
+
+                def mpack():
+                    ops._lib.call("hd_mlp_pack_input_f16x2", ops._p(x64), 1, None, 2, 37.0, ops._p(img.buf), ops._p(img.exp),
+                                  ops._p(img.amax), n, d, ops._stream())
+                report("mlp_pack_input_f16x2(f64 x)", sh, n * (8 * d + 4 * nsl + 8), timeit(mpack, a.iters))
+                dsl = (d + 31) // 32 * 32
+                report("row_pack_f16x2(hb logmap0)", sh, n * (4 * d + 4 * dsl + 8), timeit(lambda: ops.row_pack(ph, 1, 1.0), a.iters))
+            if d <= 512 and d % 4 == 0:
+                tl = torch.empty_like(x)
+
+                def tail():
+                    ops._lib.call("hd_hb_linear_tail_rows_f32", ops._p(x), ops._p(tl), n, d, ops.curv(1.0), 3, ops._stream())
+                report("hb_linear_tail_rows(flags=3)", sh, 2 * B, timeit(tail, a.iters))
+                xin = hb.proj(hb.expmap0(torch.cat([torch.zeros(n, 1, device=dev), torch.randn(n, 23, device=dev) * 0.3], 1), 1.0), 1.0)
+                wt = torch.randn(24, d, device=dev) * 0.1
+
+                def smallk():
+                    ops._lib.call("hd_hb_linear_smallk_f32", ops._p(xin), ops._p(wt), ops._p(tl), n, 24, d, ops.curv(1.0), 3,
+                                  ops._stream())
+                report("hb_linear_smallk(24 -> d, flags=3)", sh, n * 4 * (24 + d) + 4 * 24 * d, timeit(smallk, a.iters))
+                del tl, xin
             del x, p, q, ph, x64, nz, x0, out
             torch.cuda.empty_cache()
 
