@@ -398,7 +398,7 @@ def use_f16x2(x2, m):
     """HypLinear's x @ W^T goes through the f16x2 limb kernel (inference, fp32, rows short enough
     for the one-pass row producers)."""
     return (GEMM_MODE == "f16x2" and x2.dtype == torch.float32 and m.dtype == torch.float32
-            and x2.shape[1] <= ROW_PACK_MAX_DIM and x2.shape[0] > 0)
+            and 128 <= x2.shape[1] <= ROW_PACK_MAX_DIM and x2.shape[0] > 0)      # narrower rows waste the 64-lane producer
 
 
 def linear_chain(x, layers):
