@@ -1,7 +1,7 @@
 """hypdiff_amd -- MI355X-native hot path of HypDiff (hyperbolic encode + direction diffusion).
 
 Module layout mirrors the reference so existing call sites keep working:
-    hypdiff_amd.manifolds.{PoincareBall, Hyperboloid, Euclidean}
+    hypdiff_amd.manifolds.{PoincareBall, Hyperboloid}
     hypdiff_amd.layers.hyp_layers.{HypLinear, HypAgg, HypAct, HyperbolicGraphConvolution, HNNLayer}
     hypdiff_amd.models.encoders.{HGCN, HNN}
     hypdiff_amd.models.direction_diffusion.{diffusion, mlp}

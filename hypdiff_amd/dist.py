@@ -93,8 +93,13 @@ class DataParallelTrainer:
         self.bucket = GradBucket(module.parameters())
         self.opt = optimizer if optimizer is not None else torch.optim.Adam(self.bucket.params, lr=lr)
         if broadcast and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            for p in self.bucket.params:          # rank 0's initialisation everywhere
-                dist.broadcast(p.data, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            with torch.no_grad():
+                for p in self.bucket.params:      # rank 0's initialisation everywhere
+                    tmp = p.detach().clone()
+                    dist.broadcast(tmp, src=src, group=group)
+                    p.copy_(tmp)                  # in place on p itself: bumps p._version, so the caches keyed
+                                                  # on it (limb images, padded / transposed copies) are rebuilt
 
     def step(self, loss_fn):
         """loss_fn() -> scalar loss of this rank's shard.  Returns the (local) loss tensor."""

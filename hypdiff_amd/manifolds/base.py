@@ -1,6 +1,23 @@
-"""Abstract manifold API -- same method set and argument order as the reference's
-manifolds/base.py:6-88 (the drop-in boundary of the geometry layer)."""
-from torch.nn import Parameter
+"""Abstract manifold API: the method set and argument orders of the reference's
+manifolds/base.py:15-73, which are the drop-in boundary of the geometry layer.  A concrete
+manifold overrides what it accelerates; anything else raises NotImplementedError by name."""
+
+# method -> positional signature after self (per-class argument ORDER is part of the contract:
+# expmap(u, p, c) but logmap(p1, p2, c); mobius_matvec(m, x, c); sqdist(p1, p2, c))
+API = {
+    "sqdist": "p1, p2, c", "egrad2rgrad": "p, dp, c", "proj": "p, c", "proj_tan": "u, p, c",
+    "proj_tan0": "u, c", "expmap": "u, p, c", "logmap": "p1, p2, c", "expmap0": "u, c", "logmap0": "p, c",
+    "mobius_add": "x, y, c, dim=-1", "mobius_matvec": "m, x, c", "init_weights": "w, c, irange=1e-5",
+    "inner": "p, c, u, v=None, keepdim=False", "ptransp": "x, y, u, c", "ptransp0": "x, u, c",
+}
+
+
+def _abstract(name, sig):
+    def method(self, *args, **kwargs):
+        raise NotImplementedError("%s.%s(%s) is not implemented" % (type(self).__name__, name, sig))
+    method.__name__ = name
+    method.__doc__ = "%s(%s) -- manifolds/base.py" % (name, sig)
+    return method
 
 
 class Manifold(object):
@@ -8,61 +25,6 @@ class Manifold(object):
         super().__init__()
         self.eps = 10e-8
 
-    def sqdist(self, p1, p2, c):
-        raise NotImplementedError
 
-    def egrad2rgrad(self, p, dp, c):
-        raise NotImplementedError
-
-    def proj(self, p, c):
-        raise NotImplementedError
-
-    def proj_tan(self, u, p, c):
-        raise NotImplementedError
-
-    def proj_tan0(self, u, c):
-        raise NotImplementedError
-
-    def expmap(self, u, p, c):
-        raise NotImplementedError
-
-    def logmap(self, p1, p2, c):
-        raise NotImplementedError
-
-    def expmap0(self, u, c):
-        raise NotImplementedError
-
-    def logmap0(self, p, c):
-        raise NotImplementedError
-
-    def mobius_add(self, x, y, c, dim=-1):
-        raise NotImplementedError
-
-    def mobius_matvec(self, m, x, c):
-        raise NotImplementedError
-
-    def init_weights(self, w, c, irange=1e-5):
-        raise NotImplementedError
-
-    def inner(self, p, c, u, v=None, keepdim=False):
-        raise NotImplementedError
-
-    def ptransp(self, x, y, u, c):
-        raise NotImplementedError
-
-    def ptransp0(self, x, u, c):
-        raise NotImplementedError
-
-
-class ManifoldParameter(Parameter):
-    """manifolds/base.py:76-88"""
-
-    def __new__(cls, data, requires_grad, manifold, c):
-        return Parameter.__new__(cls, data, requires_grad)
-
-    def __init__(self, data, requires_grad, manifold, c):
-        self.c = c
-        self.manifold = manifold
-
-    def __repr__(self):
-        return '{} Parameter containing:\n'.format(self.manifold.name) + super(Parameter, self).__repr__()
+for _name, _sig in API.items():
+    setattr(Manifold, _name, _abstract(_name, _sig))

@@ -116,5 +116,6 @@ class Hyperboloid(Manifold):
         return self.expmap(self.ptransp0(x, u, c), x, c)
 
     def init_weights(self, w, c, irange=1e-5):
-        w.data.uniform_(-irange, irange)
+        with torch.no_grad():
+            w.uniform_(-irange, irange)     # on w itself (not .data): the version counter must move
         return w

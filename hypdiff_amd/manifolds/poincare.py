@@ -79,7 +79,8 @@ class PoincareBall(Manifold):
         return dp
 
     def init_weights(self, w, c, irange=1e-5):  # :104-106
-        w.data.uniform_(-irange, irange)
+        with torch.no_grad():
+            w.uniform_(-irange, irange)     # on w itself (not .data): the version counter must move
         return w
 
     def inner(self, x, c, u, v=None, keepdim=False):   # :120-124

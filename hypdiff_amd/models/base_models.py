@@ -53,9 +53,6 @@ class LPModel(BaseModel):
 
     def decode(self, h, idx):
         """:152-159: gather both endpoints, sqdist and the Fermi-Dirac map in ONE kernel"""
-        if self.manifold_name == 'Euclidean':
-            h = self.manifold.normalize(h)
-            return self.dc.forward(self.manifold.sqdist(h[idx[:, 0], :], h[idx[:, 1], :], self.c))
         ops._dev(h)
         idx = idx.to(device=h.device, dtype=torch.int64).contiguous()
         if torch.is_grad_enabled() and h.requires_grad:

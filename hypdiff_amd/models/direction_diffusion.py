@@ -190,10 +190,16 @@ def get_alphas(timesteps):
 
 
 class diffusion(nn.Module):
-    def __init__(self, args, dim, num_timesteps=200, prior_horizon=500, c=1.0):
+    def __init__(self, args, dim, num_timesteps=200, prior_horizon=500, c=1.0, device=None):
+        """The reference pins everything to "cuda:0" (:87,108-118); one process per GPU means the
+        rank's own device instead: `device` (default: the CURRENT device, i.e. what
+        torch.cuda.set_device(local_rank) selected).  Denoisers and schedule tables live there; the
+        tables are non-persistent buffers (state_dict keys stay the reference's), so .to() moves them."""
         super(diffusion, self).__init__()
-        device = torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
-        self.device = device
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() \
+                else torch.device("cpu")
+        device = torch.device(device)
         self.prior = 1
         self.gcn = gcndec(dim).to(device)
         self.mlp = mlp(dim).to(device)
@@ -202,7 +208,7 @@ class diffusion(nn.Module):
         self.manifold = PoincareBall()
         self.c = c
         self.dc = FermiDiracDecoder(r=args.r, t=args.t)
-        self._build_tables(num_timesteps)
+        self._build_tables(num_timesteps, device)
         self._sign_cache = None
         # data-parallel runs: `normalization` / `renormal` (:145-153) are global statistics;
         # when set, the shard-local (sum, sumsq, count) are all-reduced over this process group
@@ -210,7 +216,7 @@ class diffusion(nn.Module):
         self.sync_moments = None
 
     # ---- schedule (:94-118,173-184): fp64 on the host once, device copies cached ----
-    def _build_tables(self, T):
+    def _build_tables(self, T, device):
         alphas, betas = get_alphas(T)
         ac = torch.cumprod(alphas, dim=0)
         host = dict(
@@ -219,7 +225,11 @@ class diffusion(nn.Module):
             sqrt_recip_alphas_cumprod=torch.sqrt(1. / ac), sqrt_recipm1_alphas_cumprod=torch.sqrt(1. / ac - 1))
         self._host = {k: v.numpy().copy() for k, v in host.items()}
         for k, v in host.items():
-            setattr(self, k, v.to(self.device))
+            self.register_buffer(k, v.to(device), persistent=False)
+
+    @property
+    def device(self):
+        return self.sqrt_alphas_cumprod.device
 
     def exists(self, x):
         return x is not None
@@ -386,6 +396,7 @@ class diffusion(nn.Module):
         shape = x.shape
         img = torch.randn(shape, device=x.device) if img is None else img.clone()
         direction = self.directions(u0)
+        lables = ops.labels_dev(lables, x.device)         # one upload for the T steps of the loop
         img = self.tran_direction(direction, img, lables)
         h = self._logmap_centres(x, lables, u0)          # mutates x, as the reference does
         m = self.moments(h)
@@ -398,6 +409,9 @@ class diffusion(nn.Module):
         ret = img if not return_all_timesteps else torch.stack(imgs, dim=1)
         ret = self._apply_moments(ret, m, 1)
         lab = ops.labels_dev(lables, x.device)
+        if return_all_timesteps:
+            # (N, T+1, D): node i's centre u0[labels[i]] serves its whole (T+1, D) slice (:328-330)
+            lab = lab.repeat_interleave(ret.shape[1])
         centres = u0 if torch.is_tensor(u0) else torch.stack(list(u0))
         return ops.map_at("hd_pb_expmap_at", centres, lab, ret, 1.0)
 

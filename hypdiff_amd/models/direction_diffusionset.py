@@ -40,8 +40,8 @@ class mlp(dd.mlp):
 
 
 class diffusionset(dd.diffusion):
-    def __init__(self, args, in_dim, out_dim, num_timesteps=200, prior_horizon=500, c=1.0):
-        dd.diffusion.__init__(self, args, in_dim, num_timesteps, prior_horizon, c)
+    def __init__(self, args, in_dim, out_dim, num_timesteps=200, prior_horizon=500, c=1.0, device=None):
+        dd.diffusion.__init__(self, args, in_dim, num_timesteps, prior_horizon, c, device)
         self.mlp = mlp(in_dim, out_dim).to(self.device)
 
     # ---- folding helpers ---------------------------------------------------------------
@@ -52,7 +52,17 @@ class diffusionset(dd.diffusion):
 
     @staticmethod
     def _flat_labels(labels, k):
-        lab = labels.cpu().numpy() if torch.is_tensor(labels) else np.asarray(labels)
+        """(G, N) labels -> (G*N,) indices into the folded (G*K, D) centre / sign table.  Device
+        tensors are folded on the device (no read-back, no re-upload); a 1-D int32 device tensor
+        is taken as already folded (p_sample_loop folds once for its T steps)."""
+        if torch.is_tensor(labels):
+            if labels.dim() == 1 and labels.dtype == torch.int32 and labels.is_cuda:
+                return labels
+            if labels.is_cuda:
+                off = torch.arange(labels.shape[0], device=labels.device, dtype=torch.int64)[:, None] * k
+                return (labels.to(torch.int64) + off).reshape(-1).to(torch.int32)
+            labels = labels.numpy()
+        lab = np.asarray(labels)
         return (lab.astype(np.int64) + np.arange(lab.shape[0], dtype=np.int64)[:, None] * k).reshape(-1)
 
     def _signs(self, direction):
@@ -117,6 +127,8 @@ class diffusionset(dd.diffusion):
         g, n, d = x.shape
         img = torch.randn(x.shape, device=x.device) if img is None else img.clone()
         direction = self.directions(u0)
+        # fold + upload the labels once for the whole loop (1-D int32 device tensor passes through)
+        lables = ops.labels_dev(self._flat_labels(lables, direction[0].shape[0]), x.device)
         h = self._logmap_centres(x, lables, u0)            # mutates x like the reference
         m = self.moments(h)
         img = img + self._apply_moments(h, m, 0)

@@ -43,6 +43,12 @@ def curv(c):
     if isinstance(c, HdCurv):
         return c
     if torch.is_tensor(c):
+        if c.requires_grad and torch.is_grad_enabled():
+            # args.c=None makes the curvatures nn.Parameters (layers/hyp_layers.py:30-32); the kernels take c
+            # as a host scalar and none of the backward kernels returns d/dc -- refuse rather than train with
+            # a silently frozen curvature
+            raise NotImplementedError(
+                "trainable curvature (args.c=None) has no d/dc kernels: fix c, or run under torch.no_grad()")
         # keyed by object identity and guarded by a weak reference + version counter: a
         # freed tensor's id / storage address can be reused by a different curvature
         hit = _curv_cache.get(id(c))
@@ -68,9 +74,20 @@ def _sfx(t):
 
 
 def _dev(*ts):
+    """Every operand on ONE GPU, and that GPU the current device: the kernels are enqueued on the
+    current device's stream, so a pointer into another GPU's memory would be a cross-device access
+    without peer mapping (one process per GPU: models are built on the rank's own device)."""
+    cur = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("hypdiff_amd runs on the MI355X only: tensor is on %s (no CPU fallback)" % t.device)
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise RuntimeError("hypdiff_amd: operand on %s but the current device is cuda:%d (build the model and "
+                               "its inputs on the rank's own GPU, after torch.cuda.set_device)" % (t.device, cur))
 
 
 def _no_grad(*ts):
@@ -142,6 +159,9 @@ def map_at(name, centres, labels_dev, x, c):
     """logmap/expmap with the base point gathered per row: centres[labels[row]]."""
     _dev(centres, labels_dev, x); _no_grad(centres, x)
     x2, shape = _rows(x)
+    if labels_dev.numel() != x2.shape[0]:
+        raise ValueError("map_at: %d labels for %d rows (one label per row; repeat the labels of a node over its "
+                         "extra leading axes)" % (labels_dev.numel(), x2.shape[0]))
     ce = centres.to(x2.dtype).contiguous()
     out = torch.empty_like(x2)
     _lib.call(name + _sfx(x2), _p(ce), _p(labels_dev), ce.shape[0], _p(x2), _p(out), x2.shape[0], x2.shape[1],

@@ -59,3 +59,44 @@ def batch_graph_set(mats, sizes, feat_dim):
         feats[np.arange(off, off + s), np.arange(s)] = 1.0
         off += s
     return idx, val, (n, n), feats
+
+
+def power_law_graph(n, m, seed=1432):
+    """Config 5's graph: mean-field Barabasi-Albert.  Node i attaches m times to floor(i * u^2),
+    u ~ U(0,1) -- P(j) ~ 1 / (2 sqrt(i j)), the BA attachment kernel -- vectorised so that 10^6
+    nodes take a second on the host.  Symmetric 0/1 scipy CSR, no self loops."""
+    rs = np.random.RandomState(seed)
+    src = np.repeat(np.arange(m, n, dtype=np.int64), m)
+    dst = np.floor(src * rs.random_sample(src.shape[0]) ** 2).astype(np.int64)
+    a = sp.coo_matrix((np.ones(src.shape[0], dtype=np.float32), (src, dst)), shape=(n, n)).tocsr()
+    a = a + a.T
+    a.setdiag(0)
+    a.eliminate_zeros()
+    a.data[:] = 1.0
+    return a
+
+
+def add_hubs(adj, degrees, seed=7, cluster=None):
+    """Inject star rows into a symmetric 0/1 adjacency: for every entry of `degrees` one node
+    (spread over the index range) is joined to that many random others.  `cluster` = (first_row,
+    rows, degree) additionally gives `rows` CONSECUTIVE nodes `degree` random neighbours each (a
+    run of heavy rows that are individually below the long-row threshold)."""
+    n = adj.shape[0]
+    rs = np.random.RandomState(seed)
+    r, c = [], []
+    for i, deg in enumerate(degrees):
+        hub = (i + 1) * n // (len(degrees) + 1)
+        nb = rs.choice(n - 1, size=min(deg, n - 1), replace=False)
+        nb[nb >= hub] += 1
+        r.append(np.full(nb.shape[0], hub)); c.append(nb)
+    if cluster is not None:
+        first, rows, deg = cluster
+        for row in range(first, first + rows):
+            nb = rs.choice(n - 1, size=deg, replace=False)
+            nb[nb >= row] += 1
+            r.append(np.full(deg, row)); c.append(nb)
+    r, c = np.concatenate(r), np.concatenate(c)
+    extra = sp.coo_matrix((np.ones(r.shape[0], dtype=np.float32), (r, c)), shape=(n, n)).tocsr()
+    a = (adj + extra + extra.T).tocsr()
+    a.data[:] = 1.0
+    return a

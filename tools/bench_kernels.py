@@ -22,16 +22,7 @@ from hypdiff_amd.models.direction_diffusion import diffusion  # noqa: E402
 PEAK = 8000.0
 
 
-def power_law_graph(n, m, seed=1432):
-    """Mean-field Barabasi-Albert: node i attaches to floor(i*u^2), u ~ U(0,1), m times
-    (P(j) ~ 1/(2 sqrt(i j)), the BA attachment kernel), vectorised."""
-    rs = np.random.RandomState(seed)
-    src = np.repeat(np.arange(m, n, dtype=np.int64), m)
-    dst = np.floor(src * rs.random_sample(src.shape[0]) ** 2).astype(np.int64)
-    a = sp.coo_matrix((np.ones(src.shape[0], dtype=np.float32), (src, dst)), shape=(n, n)).tocsr()
-    a = a + a.T
-    a.data[:] = 1.0
-    return a
+power_law_graph = workloads.power_law_graph
 
 
 def timeit(fn, iters):
