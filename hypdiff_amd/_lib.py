@@ -93,6 +93,7 @@ SIGNATURES = {
     "hd_tran_direction": [P, c_int, P, P, I64, I64, I64, P],
     "hd_mlp_pack_input": [P, c_int, P, c_int, c_double, P, I64, I64, I64, P],
     "hd_moments": [P, c_int, I64, P, P, P],
+    "hd_moments_noalloc": [P, c_int, I64, P, P],
     "hd_ddpm_noise": [P, P, P, P, I64, P, I64, I64, c_int, c_double, c_double, c_double, P],
     "hd_ddpm_step": [P, P, P, c_double, c_double, c_double, P, I64, P],
     "hd_embedding_add": [P, P, P, I64, I64, I64, P],

@@ -399,6 +399,47 @@ extern "C" int hd_moments(const void* x, int dtype, int64_t count, double* works
     return check_launch("hd_moments(final)");
 }
 
+// ---- hd_moments for callers that cannot allocate (HIP graph capture, tight serving loops) ----------
+// The partial sums live in a file-scope device array instead of a caller workspace.  In host code the
+// array's name is only a stand-in; its device address is resolved per GPU with hipGetSymbolAddress the
+// first time the entry point runs on that GPU (with that GPU current), and only that pointer is handed
+// to the kernels.  Every call on a GPU shares the GPU's one array: calls that overlap on one GPU race.
+static __device__ __align__(256) double scratch[2 * kMomentBlocks];          // 16 KiB per GPU, held until exit
+constexpr int kMaxDevices = 64;
+static double* g_scratch_ptr[kMaxDevices];                                   // device address of `scratch`, per GPU
+constexpr int64_t kNoAllocMaxCount = (int64_t)1 << 32;
+
+static int scratch_of_current_device(double** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { set_error("hd_moments_noalloc: hipGetDevice: %s", hipGetErrorString(e)); return HD_EHIP; }
+    HD_REQUIRE(dev >= 0 && dev < kMaxDevices, "hd_moments_noalloc: device ordinal %d outside 0..%d", dev, kMaxDevices - 1);
+    double* p = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+    if (!p) {
+        void* q = nullptr;
+        e = hipGetSymbolAddress(&q, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !q) {
+            set_error("hd_moments_noalloc: hipGetSymbolAddress(scratch) on device %d: %s", dev, hipGetErrorString(e));
+            return HD_EHIP;
+        }
+        p = (double*)q;
+        __atomic_store_n(&g_scratch_ptr[dev], p, __ATOMIC_RELEASE);      // racing first calls resolve the same address
+    }
+    *out = p;
+    return HD_OK;
+}
+
+extern "C" int hd_moments_noalloc(const void* x, int dtype, int64_t count, double* out3, void* st) {
+    HD_REQUIRE(count >= 1 && x && out3, "hd_moments_noalloc: bad argument");
+    HD_REQUIRE(count <= kNoAllocMaxCount, "hd_moments_noalloc: count %lld exceeds the maximum of %lld elements",
+               (long long)count, (long long)kNoAllocMaxCount);
+    double* ws = nullptr;
+    if (int rc = scratch_of_current_device(&ws)) return rc;
+    // same kernels, grid and reduction tree as hd_moments; every slot the final pass reads is written by
+    // the partial pass of the same call, so nothing of the previous call's contents is consumed
+    return hd_moments(x, dtype, count, ws, out3, st);
+}
+
 extern "C" int hd_standardize(const void* x, void* out, int dtype, int64_t count, const double* moments3,
                               int inverse, void* st) {
     HD_REQUIRE(count >= 0, "hd_standardize: bad count");

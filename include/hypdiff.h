@@ -328,6 +328,15 @@ int hd_mlp_pack_input(const void* x, int x_dtype, const void* t, int t_kind, dou
  * hd_moments_workspace_doubles() doubles. */
 int64_t hd_moments_workspace_doubles(void);
 int hd_moments(const void* x, int dtype, int64_t count, double* workspace, double* out3, void* stream);
+/* hd_moments without a workspace argument and without any allocation.  NO COUNTERPART IN THE REFERENCE:
+ * it exists for callers that cannot allocate device memory -- code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  The partial sums go to a 16 KiB array that lives
+ * in the library's code object on every GPU it runs on (until the process ends); its device address is
+ * resolved once per GPU on the first call there (make that call before a capture begins).  Same
+ * kernels and reduction tree as hd_moments: out3 is bit-identical.  count <= 2^32 elements, else
+ * status 1.  Calls on ONE GPU share that GPU's array: calls that overlap there (two streams, two
+ * threads) race -- serialise them.  Calls no hipMalloc / hipFree or any allocating routine. */
+int hd_moments_noalloc(const void* x, int dtype, int64_t count, double* out3, void* stream);
 /* inverse == 0: (x - mean) / std ; inverse != 0: x * std + mean ; unbiased std, from moments3 */
 int hd_standardize(const void* x, void* out, int dtype, int64_t count, const double* moments3, int inverse,
                    void* stream);
