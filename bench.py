@@ -215,7 +215,11 @@ def main():
                     help="skip the secondary leg that issues encode and p_sample on two HIP streams")
     ap.add_argument("--no-exact-leg", action="store_true", help="skip the comparison legs on the other fp32 GEMM kernels")
     ap.add_argument("--train-steps", type=int, default=20, help="steps of the secondary training leg (0 = skip)")
+    ap.add_argument("--no-secondary", action="store_true", help="headline steps only (profiling runs)")
     a = ap.parse_args()
+    if a.no_secondary:
+        a.no_overlap_leg = a.no_exact_leg = True
+        a.train_steps = 0
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -21,6 +21,12 @@ from . import _lib, ops
 
 GELU, RES, LIN = 1, 2, 0        # layer kinds = epilogue codes of hd_gemm_f32
 
+# Set by dist.DataParallelTrainer around loss.backward(): an object with view_for(param) -> fp32 view of
+# the flat gradient bucket (or None) and delivered(param).  LinearStack.backward then writes a layer's
+# dW / db straight into the bucket and reports it, so the bucket's chunk can start its all-reduce while
+# the layers below are still in their GEMMs.  Parameters are assumed to enter the graph once per step.
+GRAD_SINK = None
+
 
 def _ws(n, dtype, device):
     return torch.empty(max(int(n), 1), dtype=dtype, device=device)
@@ -58,6 +64,9 @@ def gemm_tn(a, b, out=None):
             return res.contiguous()
         out.copy_(res)
         return out
+    if out is not None and (out.data_ptr() % 16 or not out.is_contiguous()):
+        out.copy_(gemm_tn(a, b))                  # the kernel stores 16-byte rows
+        return out
     if out is None:
         out = torch.empty(P, Q, dtype=torch.float32, device=a.device)
     ws = _ws(_lib.load().hd_gemm_tn_workspace_floats(R, P, Q), torch.float32, a.device)
@@ -80,9 +89,10 @@ def transpose(w):
     return out
 
 
-def colsum(x):
+def colsum(x, out=None):
     M, N = x.shape
-    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=x.device)
     ws = _ws(_lib.load().hd_colsum_workspace_floats(M, N), torch.float32, x.device)
     _lib.call("hd_colsum_f32", ops._p(x), ops._p(out), M, N, x.stride(0), ops._p(ws), ops._stream())
     return out
@@ -113,6 +123,7 @@ class LinearStack(torch.autograd.Function):
             zs.append(z)
             h = out
         ctx.kinds = kinds
+        ctx.params = params            # the parameter objects themselves (GRAD_SINK looks them up by identity)
         ctx.need_x = x.requires_grad
         ctx.wshapes = [tuple(w.shape) for w in ws_]
         ctx.save_for_backward(*xs, *[z for z in zs if z is not None], *wpad)
@@ -140,10 +151,23 @@ class LinearStack(torch.autograd.Function):
             raise NotImplementedError("LinearStack: the last layer must be linear")
         for l in range(top, -1, -1):
             x_l, w = xs[l], ws_[l]
-            dw = gemm_tn(dz, x_l)
             shp = ctx.wshapes[l]
-            grads[2 * l] = dw if tuple(dw.shape) == shp else dw[:, :shp[1]].contiguous()
-            grads[2 * l + 1] = colsum(dz)
+            sink = GRAD_SINK
+            wp, bp = ctx.params[2 * l], ctx.params[2 * l + 1]
+            wv = sink.view_for(wp) if sink is not None else None
+            bv = sink.view_for(bp) if sink is not None else None
+            if wv is not None and bv is not None:
+                if shp[1] == x_l.shape[1]:
+                    gemm_tn(dz, x_l, out=wv)
+                else:                                       # zero-padded first layer: slice the pad columns off
+                    wv.copy_(gemm_tn(dz, x_l)[:, :shp[1]])
+                colsum(dz, out=bv)
+                sink.delivered(bp)
+                sink.delivered(wp)
+            else:
+                dw = gemm_tn(dz, x_l)
+                grads[2 * l] = dw if tuple(dw.shape) == shp else dw[:, :shp[1]].contiguous()
+                grads[2 * l + 1] = colsum(dz)
             if l == 0 and not ctx.need_x:
                 break
             wt = transpose(w)                                    # (K_l, N_l): contraction over N_l

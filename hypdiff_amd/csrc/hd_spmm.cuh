@@ -49,7 +49,7 @@ __device__ __forceinline__ void agg_epilogue(TL& acc, int epi, const Curv& cin, 
 
 // acc += sum over entries [k0, k1) read through (cols, vals) with index offset `off`
 template <typename T, int DEPTH, class TL, class CI, class VI>
-__device__ __forceinline__ void gather_accumulate(TL& acc, const T* __restrict__ x, int d, int k0, int k1,
+__device__ __forceinline__ void gather_accumulate(TL& acc, const T* __restrict__ x, int d, int64_t ldx, int k0, int k1,
                                                   const CI& cols, const VI& vals) {
     for (; k0 < k1; k0 += DEPTH) {
         TL t[DEPTH];
@@ -58,7 +58,7 @@ __device__ __forceinline__ void gather_accumulate(TL& acc, const T* __restrict__
         for (int u = 0; u < DEPTH; ++u) {
             t[u].init(d);
             if (k0 + u < k1) {
-                t[u].load(x + (int64_t)cols(k0 + u) * d);
+                t[u].load(x + (int64_t)cols(k0 + u) * ldx);
                 w[u] = vals(k0 + u);
             } else {
                 t[u].zero();
@@ -76,8 +76,8 @@ template <class M, typename T, int G, int VEC, int REGS>
 __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 ? 4 : 1)) void spmm_rows(const int32_t* __restrict__ rowptr,
                                                     const int32_t* __restrict__ col,
                                                     const T* __restrict__ val, const T* __restrict__ x,
-                                                    T* __restrict__ out, int64_t n, int d, int epi, Curv cin,
-                                                    Curv cout, int act, int skip_long) {
+                                                    T* __restrict__ out, int64_t n, int d, int64_t ldx, int64_t ldo,
+                                                    int epi, Curv cin, Curv cout, int act, int skip_long) {
     constexpr int RPB = kBlock / G;
     constexpr int DEPTH = depth_for<T, REGS>();
     __shared__ int32_t s_col[kStage];
@@ -104,15 +104,15 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 ? 4 : 1)) void spmm_rows(co
                 s_val[i] = val[seg0 + i];
             }
             __syncthreads();
-            gather_accumulate<T, DEPTH>(acc, x, d, rs, re, [&](int k) { return s_col[k - seg0]; },
+            gather_accumulate<T, DEPTH>(acc, x, d, ldx, rs, re, [&](int k) { return s_col[k - seg0]; },
                                  [&](int k) { return s_val[k - seg0]; });
         } else {
             // a long (unsplit) row in this block: read the lists straight from global memory
-            gather_accumulate<T, DEPTH>(acc, x, d, rs, re, [&](int k) { return col[k]; }, [&](int k) { return val[k]; });
+            gather_accumulate<T, DEPTH>(acc, x, d, ldx, rs, re, [&](int k) { return col[k]; }, [&](int k) { return val[k]; });
         }
         if (valid) {
             agg_epilogue<M, T>(acc, epi, cin, cout, act);
-            acc.store(out + row * d);
+            acc.store(out + row * ldo);
         }
     }
 }
@@ -125,8 +125,8 @@ __global__ __launch_bounds__(kLongWaves * 64) void spmm_long(const int32_t* __re
                                                              const int32_t* __restrict__ rowptr,
                                                              const int32_t* __restrict__ col,
                                                              const T* __restrict__ val, const T* __restrict__ x,
-                                                             T* __restrict__ out, int d, int epi, Curv cin,
-                                                             Curv cout, int act) {
+                                                             T* __restrict__ out, int d, int64_t ldx, int64_t ldo,
+                                                             int epi, Curv cin, Curv cout, int act) {
     using TL = Tile<T, 64, VEC, REGS>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* part = reinterpret_cast<T*>(smem);                 // [kLongWaves][d]
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void spmm_long(const int32_t* __re
     TL acc;
     acc.init(d);
     acc.zero();
-    gather_accumulate<T, depth_for<T, REGS>()>(acc, x, d, k0, k1, [&](int k) { return col[k]; }, [&](int k) { return val[k]; });
+    gather_accumulate<T, depth_for<T, REGS>()>(acc, x, d, ldx, k0, k1, [&](int k) { return col[k]; }, [&](int k) { return val[k]; });
     acc.store(part + (size_t)wave * d);
     __syncthreads();
     if (wave == 0) {
@@ -152,20 +152,24 @@ __global__ __launch_bounds__(kLongWaves * 64) void spmm_long(const int32_t* __re
             for (int i = 0; i < TL::kRegs; ++i) acc.v[i] += tmp.v[i];
         }
         agg_epilogue<M, T>(acc, epi, cin, cout, act);
-        acc.store(out + (int64_t)row * d);
+        acc.store(out + (int64_t)row * ldo);
     }
 }
 
 template <class M, typename T>
 int launch_spmm(const char* name, const int32_t* rowptr, const int32_t* col, const void* val, const void* x,
                 void* out, int64_t n, int64_t d, int epi, hd_curv ci, hd_curv co, int act,
-                const int32_t* long_rows, int64_t n_long, void* st) {
+                const int32_t* long_rows, int64_t n_long, void* st, int64_t ldx = 0, int64_t ldo = 0) {
     HD_REQUIRE(n >= 0 && d >= 1, "%s: bad shape rows=%lld dim=%lld", name, (long long)n, (long long)d);
+    if (ldx == 0) ldx = d;                              // row pitches (elements); 0 = contiguous rows
+    if (ldo == 0) ldo = d;
+    HD_REQUIRE(ldx >= d && ldo >= d, "%s: row pitch smaller than dim", name);
     if (n == 0) return HD_OK;
     HD_REQUIRE(rowptr && col && val && x && out, "%s: null pointer", name);
     HD_REQUIRE(x != out, "%s: out must not alias x (rows are gathered)", name);
     HD_REQUIRE(n_long >= 0 && (n_long == 0 || long_rows), "%s: long-row list missing", name);
-    RowCfg c = pick_cfg<T>(d, is_aligned16(x) && is_aligned16(out));
+    const bool al16 = is_aligned16(x) && is_aligned16(out) && ldx % VecOf<T>::N == 0 && ldo % VecOf<T>::N == 0;
+    RowCfg c = pick_cfg<T>(d, al16);
     HD_REQUIRE(c.ok, "%s: dim=%lld exceeds the register-tile limit", name, (long long)d);
     const Curv cin{ci.c, ci.sqrt_c, ci.K, ci.sqrt_K}, cout{co.c, co.sqrt_c, co.K, co.sqrt_K};
     const int ch = (int)((d + (int64_t)c.g * c.vec - 1) / ((int64_t)c.g * c.vec));
@@ -176,19 +180,19 @@ int launch_spmm(const char* name, const int32_t* rowptr, const int32_t* col, con
         constexpr int R0 = V < 4 ? 4 : V;              // smallest specialisation
         if (sizeof(T) == 4 && need <= R0)
             spmm_rows<M, T, G, V, R0><<<grid_for_rows(n, G), kBlock, 0, s>>>(
-                rowptr, col, (const T*)val, (const T*)x, (T*)out, n, (int)d, epi, cin, cout, act, n_long > 0);
+                rowptr, col, (const T*)val, (const T*)x, (T*)out, n, (int)d, ldx, ldo, epi, cin, cout, act, n_long > 0);
         else if (sizeof(T) == 4 && need <= 8)
             spmm_rows<M, T, G, V, 8><<<grid_for_rows(n, G), kBlock, 0, s>>>(
-                rowptr, col, (const T*)val, (const T*)x, (T*)out, n, (int)d, epi, cin, cout, act, n_long > 0);
+                rowptr, col, (const T*)val, (const T*)x, (T*)out, n, (int)d, ldx, ldo, epi, cin, cout, act, n_long > 0);
         else
             spmm_rows<M, T, G, V, kRegs><<<grid_for_rows(n, G), kBlock, 0, s>>>(
-                rowptr, col, (const T*)val, (const T*)x, (T*)out, n, (int)d, epi, cin, cout, act, n_long > 0);
+                rowptr, col, (const T*)val, (const T*)x, (T*)out, n, (int)d, ldx, ldo, epi, cin, cout, act, n_long > 0);
         return check_launch(name);
     });
     if (rc || n_long == 0) return rc;
     // long rows: G = 64 always; scalar loads unless 16-byte rows
     const int V = VecOf<T>::N;
-    const bool vec = is_aligned16(x) && is_aligned16(out) && d % V == 0;
+    const bool vec = al16 && d % V == 0;
     const int64_t lanes = vec ? d / V : d;
     HD_REQUIRE(lanes <= 64LL * (kRegs / (vec ? V : 1)), "%s: dim too large for the long-row kernel", name);
     const size_t lds = (size_t)kLongWaves * d * sizeof(T);
@@ -196,7 +200,7 @@ int launch_spmm(const char* name, const int32_t* rowptr, const int32_t* col, con
     const int need64 = (int)((lanes + 63) / 64) * (vec ? V : 1);
 #define HD_LONG(VV, RR)                                                                                   \
     spmm_long<M, T, VV, RR><<<(unsigned)n_long, kLongWaves * 64, lds, s>>>(                               \
-        long_rows, rowptr, col, (const T*)val, (const T*)x, (T*)out, (int)d, epi, cin, cout, act)
+        long_rows, rowptr, col, (const T*)val, (const T*)x, (T*)out, (int)d, ldx, ldo, epi, cin, cout, act)
     if (vec) {
         if (sizeof(T) == 4 && need64 <= 4) HD_LONG(VecOf<T>::N, 4);
         else if (sizeof(T) == 4 && need64 <= 8) HD_LONG(VecOf<T>::N, 8);
@@ -218,6 +222,13 @@ int launch_spmm(const char* name, const int32_t* rowptr, const int32_t* col, con
         hd_curv one{1, 1, 1, 1};                                                                           \
         return hd::launch_spmm<hd::PB<T>, T>("hd_spmm_csr_" #sfx, rowptr, col, val, x, out, n, d, hd::E_NONE, one, \
                                              one, 0, long_rows, n_long, st);                               \
+    }                                                                                                      \
+    extern "C" int hd_spmm_csr_strided_##sfx(const int32_t* rowptr, const int32_t* col, const void* val,  \
+                                             const void* x, int64_t ldx, void* out, int64_t ldo, int64_t n,  \
+                                             int64_t d, const int32_t* long_rows, int64_t n_long, void* st) { \
+        hd_curv one{1, 1, 1, 1};                                                                           \
+        return hd::launch_spmm<hd::PB<T>, T>("hd_spmm_csr_strided_" #sfx, rowptr, col, val, x, out, n, d, hd::E_NONE, \
+                                             one, one, 0, long_rows, n_long, st, ldx, ldo);                \
     }                                                                                                      \
     extern "C" int hd_pb_agg_##sfx(const int32_t* rowptr, const int32_t* col, const void* val,            \
                                    const void* xt, void* out, int64_t n, int64_t d, hd_curv c_in,          \

@@ -8,12 +8,26 @@ Three shardings:
     (models/direction_diffusion.py:145-153): all-reduce the shard-local (sum, sumsq, count).
   * data-parallel training: one flat fp32 gradient bucket, one all-reduce per step.
   * one large graph (configs 4-5): contiguous row blocks of the CSR; HypLinear / HypAct are
-    row-local, HypAgg needs the tangent rows of remote columns -> one all-gather of the
-    (N/P, d) tangent block per layer, then the local SpMM over global column indices.
+    row-local, HypAgg needs the tangent rows of remote columns -> the (N/P, d) tangent block of
+    every rank is all-gathered per layer IN COLUMN SLABS on RCCL's stream while the local SpMM
+    (global column indices) already runs on the slabs that have landed.
+
+Overlap: both collectives run asynchronously (torch's NCCL work handles): the gradient bucket is
+reduced in chunks as soon as the backward kernels have produced them (last layers first) while the
+GEMMs of the earlier layers still run; the tangent all-gather of slab k+1 is on the wire while
+slab k is aggregated.
 """
 import numpy as np
 import torch
 import torch.distributed as dist
+
+# tests: issue the collectives even in a world of ONE rank, so that the RCCL code path executes on a
+# single-GPU box (a world of one normally short-circuits every collective)
+FORCE_COLLECTIVES = False
+
+
+def _collective(group=None):
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or FORCE_COLLECTIVES)
 
 
 def world():
@@ -34,25 +48,45 @@ def allreduce_moments(m, group=None):
     24 bytes on the wire; every rank then standardises with the global mean/std and
     obtains exactly what a single GPU would compute on the concatenated rows (up to the
     fp64 summation order)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _collective(group):
         dist.all_reduce(m, op=dist.ReduceOp.SUM, group=group)
     return m
 
 
 class GradBucket:
-    """All gradients of a module as ONE flat fp32 buffer (2.8 M elements for the mlp
-    denoiser at D=512 ~ 11 MB): a single ring all-reduce per step instead of one per
-    parameter -- xGMI links are point-to-point, so few large messages beat many small."""
+    """All gradients of a module as ONE flat fp32 buffer (2.8 M elements for the mlp denoiser at
+    D=512 ~ 11 MB; 6.4 M ~ 25 MB for ddpm.Backbone).
 
-    def __init__(self, params):
+    The buffer is reduced in a few large chunks rather than per parameter -- xGMI links are
+    point-to-point, so a ring all-reduce is per-link bound and few large messages beat many small
+    ones -- and the chunks are cut along parameter boundaries at >= `chunk_bytes`, so that a chunk can
+    leave as soon as the backward pass has produced its last gradient (`ready()`), overlapped with
+    the GEMMs of the layers below.  Gradients are views into the buffer: no pack / unpack copies."""
+
+    def __init__(self, params, chunk_bytes=4 << 20):
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else "cpu"
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.offsets = {}
         off = 0
-        for p in self.params:       # gradients become views into the bucket: no pack/unpack copies
+        for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.offsets[id(p)] = (off, off + p.numel())
             off += p.numel()
+        # chunks: runs of consecutive parameters, walked from the END of the parameter list (the order in
+        # which backward produces gradients), closed once they hold chunk_bytes
+        self.chunks, hi, acc = [], n, 0
+        for p in reversed(self.params):
+            acc += p.numel() * 4
+            lo = self.offsets[id(p)][0]
+            if acc >= chunk_bytes:
+                self.chunks.append((lo, hi))
+                hi, acc = lo, 0
+        if hi > 0:
+            self.chunks.append((0, hi))
+        self._pending = {c: sum(1 for p in self.params if c[0] <= self.offsets[id(p)][0] < c[1]) for c in self.chunks}
+        self._left, self._works, self._hooks = {}, [], []
 
     def zero_(self):
         self.flat.zero_()
@@ -60,19 +94,74 @@ class GradBucket:
     def rebind(self):
         """autograd accumulates into an existing .grad in place, which keeps the views; if a
         gradient was replaced by a fresh tensor anyway, copy it back into the bucket."""
-        off = 0
         for p in self.params:
-            n = p.numel()
-            view = self.flat[off:off + n].view_as(p)
+            lo, hi = self.offsets[id(p)]
+            view = self.flat[lo:hi].view_as(p)
             if p.grad is None:
                 p.grad = view
             elif p.grad.data_ptr() != view.data_ptr():
                 view.copy_(p.grad)
                 p.grad = view
-            off += n
+
+    # ---- overlapped reduction -------------------------------------------------------------
+    def arm(self, group=None):
+        """Before backward: count down the parameters of every chunk as their gradients arrive
+        (post-accumulate hooks) and launch the chunk's all-reduce when it is complete."""
+        self._left = dict(self._pending)
+        self._works = []
+        self._group = group
+        if not self._hooks:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def view_for(self, p):
+        """The bucket view a backward kernel may write parameter p's gradient into directly (armed
+        buckets only; hypdiff_amd.autograd.GRAD_SINK), or None."""
+        if not self._left or id(p) not in self.offsets:
+            return None
+        lo, hi = self.offsets[id(p)]
+        return self.flat[lo:hi].view_as(p)
+
+    def delivered(self, p):
+        """p's gradient has been written into view_for(p) (enqueued on the current stream)"""
+        self._on_grad(p)
+
+    def _on_grad(self, p):
+        if not self._left or id(p) not in self.offsets:
+            return
+        lo = self.offsets[id(p)][0]
+        for c in self.chunks:
+            if c[0] <= lo < c[1]:
+                self._left[c] -= 1
+                if self._left[c] == 0:
+                    self._launch(c)
+                return
+
+    def _launch(self, c):
+        view = self.flat[c[0]:c[1]]
+        # a gradient that autograd replaced instead of accumulating in place has to be copied in first
+        for p in self.params:
+            lo, hi = self.offsets[id(p)]
+            if c[0] <= lo < c[1] and p.grad is not None and p.grad.data_ptr() != self.flat[lo:hi].data_ptr():
+                self.flat[lo:hi].view_as(p).copy_(p.grad)
+                p.grad = self.flat[lo:hi].view_as(p)
+        view.div_(dist.get_world_size(self._group))
+        self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self._group, async_op=True))
+
+    def finish(self):
+        """After backward: reduce whatever no hook has sent (parameters without a gradient this step)
+        and wait for every chunk (the waits only order the current stream behind RCCL's)."""
+        for c, left in list(self._left.items()):
+            if left > 0:
+                self._launch(c)
+        self._left = {}
+        for w in self._works:
+            w.wait()
+        self._works = []
 
     def allreduce_mean_(self, group=None, async_op=False):
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        """one blocking all-reduce of the whole bucket (the non-overlapped form)"""
+        if not _collective(group):
             return None
         self.flat.div_(dist.get_world_size(group))
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
@@ -83,16 +172,17 @@ class DataParallelTrainer:
     loss -> backward -> Adam on one device; here every rank does that on its own shard of the
     graph set and the gradients are averaged in between).
 
-    All gradients live in one flat fp32 bucket (the HIP backward kernels' outputs are
-    accumulated into views of it), so the only collective of a step is ONE all-reduce of
-    ~11 MB (mlp, D=512) / ~25 MB (ddpm.Backbone) over RCCL; the optimizer is torch's Adam on
-    every rank (identical updates: weights never need a broadcast after the first)."""
+    All gradients live in one flat fp32 bucket (the HIP backward kernels' outputs are accumulated
+    into views of it).  With `overlap` (default) the bucket leaves in >= 4 MB chunks over RCCL while
+    backward is still running -- 3 chunks for the mlp at D=512 (11 MB), 6 for ddpm.Backbone (25 MB);
+    otherwise as ONE all-reduce after backward.  The optimizer is torch's Adam on every rank
+    (identical updates: weights never need a broadcast after the first)."""
 
-    def __init__(self, module, lr=1e-3, group=None, optimizer=None, broadcast=True):
-        self.module, self.group = module, group
+    def __init__(self, module, lr=1e-3, group=None, optimizer=None, broadcast=True, overlap=True):
+        self.module, self.group, self.overlap = module, group, overlap
         self.bucket = GradBucket(module.parameters())
         self.opt = optimizer if optimizer is not None else torch.optim.Adam(self.bucket.params, lr=lr)
-        if broadcast and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if broadcast and _collective(group):
             src = dist.get_global_rank(group, 0) if group is not None else 0
             with torch.no_grad():
                 for p in self.bucket.params:      # rank 0's initialisation everywhere
@@ -105,9 +195,19 @@ class DataParallelTrainer:
         """loss_fn() -> scalar loss of this rank's shard.  Returns the (local) loss tensor."""
         self.bucket.zero_()
         loss = loss_fn()
-        loss.backward()
-        self.bucket.rebind()
-        self.bucket.allreduce_mean_(self.group)
+        if self.overlap and _collective(self.group):
+            from . import autograd as hag
+            self.bucket.arm(self.group)
+            hag.GRAD_SINK = self.bucket           # the stack's backward writes dW / db straight into the bucket
+            try:
+                loss.backward()
+            finally:
+                hag.GRAD_SINK = None
+            self.bucket.finish()
+        else:
+            loss.backward()
+            self.bucket.rebind()
+            self.bucket.allreduce_mean_(self.group)
         self.opt.step()
         return loss.detach()
 
@@ -133,19 +233,46 @@ class RowShardedAdj:
         self.local_values = values[a:b]
         self.local_shape = (self.rows_per_rank, self.rows_per_rank * world_size)
 
+    def _padded(self, x_local):
+        if x_local.shape[0] == self.rows_per_rank:
+            return x_local
+        pad = torch.zeros(self.rows_per_rank - x_local.shape[0], x_local.shape[1], dtype=x_local.dtype,
+                          device=x_local.device)
+        return torch.cat([x_local, pad], 0)
+
     def gather_rows(self, x_local, group=None):
         """(rows_per_rank, d) block of every rank -> (rows_per_rank * P, d), rank-major = global
         row order.  Direct all-gather: on the full xGMI mesh every rank writes its block to
         its 7 peers concurrently."""
-        if x_local.shape[0] != self.rows_per_rank:
-            pad = torch.zeros(self.rows_per_rank - x_local.shape[0], x_local.shape[1], dtype=x_local.dtype,
-                              device=x_local.device)
-            x_local = torch.cat([x_local, pad], 0)
-        if self.world == 1:
+        x_local = self._padded(x_local)
+        if self.world == 1 and not FORCE_COLLECTIVES:
             return x_local
         out = torch.empty(self.rows_per_rank * self.world, x_local.shape[1], dtype=x_local.dtype,
                           device=x_local.device)
         dist.all_gather_into_tensor(out, x_local.contiguous(), group=group)
+        return out
+
+    def gather_slabs(self, x_local, n_slabs, group=None):
+        """The same all-gather cut into column slabs, every slab an asynchronous collective of its own:
+        returns [(col_lo, col_hi, gathered (rows_per_rank * P, width) tensor, work handle or None)].
+        RCCL runs the slabs back to back on its own stream; the caller waits for slab k only (which
+        orders the compute stream behind that one collective) and aggregates it while slabs k+1.. are
+        still on the wire.  Slab widths are multiples of 4 columns (16-byte rows)."""
+        x_local = self._padded(x_local)
+        d = x_local.shape[1]
+        n_slabs = max(1, min(n_slabs, d // 4 if d >= 4 else 1))
+        width = -(-d // n_slabs)
+        width = (width + 3) // 4 * 4
+        out = []
+        for lo in range(0, d, width):
+            hi = min(d, lo + width)
+            part = x_local[:, lo:hi].contiguous()
+            if self.world == 1 and not FORCE_COLLECTIVES:
+                out.append((lo, hi, part, None))
+                continue
+            full = torch.empty(self.rows_per_rank * self.world, hi - lo, dtype=x_local.dtype, device=x_local.device)
+            work = dist.all_gather_into_tensor(full, part, group=group, async_op=True)
+            out.append((lo, hi, full, work))
         return out
 
     def aggregate(self, xt_local, spmm, group=None):
@@ -157,28 +284,44 @@ class RowShardedAdj:
         out = spmm(self.local_indices, self.local_values, self.local_shape, full)
         return out[: self.hi - self.lo]
 
+    def aggregate_slabs(self, xt_local, spmm, n_slabs=4, group=None):
+        """aggregate() with the all-gather pipelined against the SpMM in column slabs.  A feature
+        column's sum does not involve the other columns, so the result is bit-identical."""
+        n_loc = self.hi - self.lo
+        outs = []
+        for lo, hi, full, work in self.gather_slabs(xt_local, n_slabs, group):
+            if work is not None:
+                work.wait()
+            outs.append(spmm(self.local_indices, self.local_values, self.local_shape, full)[:n_loc])
+        return torch.cat(outs, 1)
 
-def sharded_hgcn_encode(encoder, x_local, sharded_adj, group=None):
+
+def sharded_hgcn_encode(encoder, x_local, sharded_adj, group=None, n_slabs=4):
     """HGCN.encode (models/encoders.py:115-119) for ONE graph whose rows are split over the ranks
     (config 5).  The input lift, HypLinear and HypAct are row-local; HypAgg needs the tangent rows
     of remote columns, so every layer is
 
         local rows:  lift / HypLinear tail -> tangent block (N/P, d)
-        all ranks :  ONE all-gather of the tangent blocks (RCCL over xGMI)
-        local rows:  CSR SpMM over global columns with expmap0 / proj / HypAct fused
+        all ranks :  all-gather of the tangent blocks over RCCL / xGMI, in n_slabs column slabs
+        local rows:  CSR SpMM over global columns on slab k while slab k+1 is on the wire, then
+                     expmap0 / proj / HypAct on the assembled rows (hd_*_agg_tail)
 
-    `x_local` holds this rank's rows of the features (Hyperboloid: zero time column already
-    prepended).  Per row the summation order is that of the 1-GPU kernel, so the result is
-    bit-identical to encoder.encode on the whole graph.  Inference path (torch.no_grad())."""
+    With one slab (or a world of one rank) the aggregate is the single fused kernel of the 1-GPU
+    path.  `x_local` holds this rank's rows of the features (Hyperboloid: zero time column already
+    prepended).  Per row and feature the summation order is that of the 1-GPU kernel, so the result
+    is bit-identical to encoder.encode on the whole graph.  Inference path (torch.no_grad())."""
     from .models.encoders import _lift
     n_loc = sharded_adj.hi - sharded_adj.lo
     assert x_local.shape[0] == n_loc, (x_local.shape, n_loc)
-    shard_csr(sharded_adj, x_local.device)
-    csr = sharded_adj._csr
+    csr = shard_csr(sharded_adj, x_local.device)
     h = _lift(encoder.manifold, x_local, encoder.curvatures[0])
+    pipelined = n_slabs > 1 and (sharded_adj.world > 1 or FORCE_COLLECTIVES)
     for layer in encoder.layers:
         xt = layer.linear.forward(h, _tangent=True)
-        h = shard_aggregate(layer, csr, sharded_adj.gather_rows(xt, group), n_loc)
+        if pipelined and xt.shape[1] >= 8 and xt.shape[1] % 4 == 0:
+            h = shard_aggregate_slabs(layer, csr, sharded_adj.gather_slabs(xt, n_slabs, group), n_loc)
+        else:
+            h = shard_aggregate(layer, csr, sharded_adj.gather_rows(xt, group), n_loc)
     return h
 
 
@@ -203,4 +346,25 @@ def shard_aggregate(layer, csr, xt_full, n_loc):
         out = ops.agg(man.abi, csr, xt_full, layer.agg.c, layer.hyp_act.c_out, code)
     else:
         out = layer.hyp_act.forward(ops.agg(man.abi, csr, xt_full, layer.agg.c))
+    return out[:n_loc]
+
+
+def shard_aggregate_slabs(layer, csr, slabs, n_loc):
+    """shard_aggregate on column slabs as they arrive: plain SpMM of slab k into columns [lo, hi) of
+    the support rows (hd_spmm_csr_strided), then the row tail (expmap0 -> proj [-> HypAct]) in one
+    pass over the assembled support (hd_*_agg_tail) -- the same values as the fused aggregate."""
+    from . import ops
+    from .layers.hyp_layers import act_code
+    code = act_code(layer.hyp_act.act)
+    man = layer.agg.manifold
+    d = slabs[-1][1]
+    full0 = slabs[0][2]
+    sup = torch.empty(csr.shape[0], d, dtype=full0.dtype, device=full0.device)
+    for lo, hi, full, work in slabs:
+        if work is not None:
+            work.wait()                         # the compute stream waits for THIS slab's collective only
+        ops.spmm_into(csr, full, sup, lo)
+    out = ops.agg_tail(man.abi, sup, layer.agg.c, layer.hyp_act.c_out if code is not None else None, code)
+    if code is None:
+        out = layer.hyp_act.forward(out)
     return out[:n_loc]

@@ -18,11 +18,14 @@ ACT_CODES = {"identity": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "elu": 4, "leaky
 
 _curv_cache = {}
 GEMM_EVENTS = None      # set to a list by bench.py to time every hd_gemm_f32 launch
-# fp32 GEMM kernels: "bf16x3" = fp32-accurate 3-limb split on the bf16 matrix cores (6 MFMAs per
-# product term, csrc/gemm_split.hip, csrc/gemm_limbs.hip); "f16x2" = the denoiser chains carry two
-# row-scaled fp16 limbs instead (3 MFMAs per product term, csrc/gemm_limbs.hip), everything else as
-# bf16x3; "exact" = v_mfma_f32_32x32x2_f32 (csrc/gemm.hip).
-GEMM_MODE = os.environ.get("HD_GEMM_MODE", "f16x2")
+# fp32 GEMM kernels.  "bf16x3" (default) = fp32-faithful 3-limb split on the bf16 matrix cores: every
+# operand element keeps its own 24 significant bits, 6 exact limb products per fp32 product
+# (csrc/gemm_limbs.hip, csrc/gemm_split.hip).  "exact" = v_mfma_f32_32x32x2_f32 (csrc/gemm.hip), bit
+# for bit an fmaf chain.  "f16x2" = opt-in: inference GEMMs carry two fp16 limbs of the row scaled by
+# a power of two (22 bits relative to the ROW maximum -- block floating point, narrower than IEEE
+# fp32 element by element, although the contraction's error stays inside the fp32 bound), 3 limb
+# products per fp32 product; residual chains and training stay on bf16x3.
+GEMM_MODE = os.environ.get("HD_GEMM_MODE", "bf16x3")
 
 
 def gemm_symbol():
@@ -540,6 +543,31 @@ def spmm(csr, x):
     out = torch.empty(csr.shape[0], x2.shape[1], dtype=x2.dtype, device=x2.device)
     _lib.call("hd_spmm_csr" + _sfx(x2), _p(csr.rowptr), _p(csr.col), _p(csr.values(x2.dtype)), _p(x2), _p(out),
               csr.shape[0], x2.shape[1], _p(csr.long_rows) if csr.n_long else None, csr.n_long, _stream())
+    return out
+
+
+def spmm_into(csr, x, out, col0):
+    """out[:, col0:col0 + x.shape[1]] = adj @ x for a column slab x (contiguous) of wider rows
+    (hd_spmm_csr_strided: same per-column summation order as spmm on whole rows)."""
+    _dev(x, out)
+    assert x.is_contiguous() and out.is_contiguous() and out.dtype == x.dtype and out.shape[0] == csr.shape[0]
+    w = x.shape[1]
+    assert 0 <= col0 and col0 + w <= out.shape[1]
+    dst = out[:, col0:]
+    _lib.call("hd_spmm_csr_strided" + _sfx(x), _p(csr.rowptr), _p(csr.col), _p(csr.values(x.dtype)), _p(x), w,
+              ctypes.c_void_p(dst.data_ptr()), out.shape[1], csr.shape[0], w,
+              _p(csr.long_rows) if csr.n_long else None, csr.n_long, _stream())
+    return out
+
+
+def agg_tail(manifold, s, c_in, c_out=None, act_code=None):
+    """proj(expmap0(s)) [+ HypAct] on a stored aggregate s = spmm(adj, xt) (hd_*_agg_tail)."""
+    _dev(s)
+    s2 = s.contiguous()
+    out = torch.empty_like(s2)
+    fuse = act_code is not None
+    _lib.call(f"hd_{manifold}_agg_tail" + _sfx(s2), _p(s2), _p(out), s2.shape[0], s2.shape[1], curv(c_in),
+              curv(c_out if fuse else c_in), act_code if fuse else 0, 1 if fuse else 0, _stream())
     return out
 
 

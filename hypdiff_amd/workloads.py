@@ -100,3 +100,43 @@ def add_hubs(adj, degrees, seed=7, cluster=None):
     a = (adj + extra + extra.T).tocsr()
     a.data[:] = 1.0
     return a
+
+
+def community_graph_set(n_graphs=1000, total_nodes=7850, total_edges=4684, n_min=2, n_max=14, seed=1432):
+    """SynCommunity1000-shaped set (1000 graphs, 2-14 nodes, sum N = 7 850,
+    sum E = 4 684 -- fewer edges than nodes, so the graphs are sparse and partly disconnected): two
+    communities per graph, edges drawn among intra-community pairs plus one bridge, nudged to the
+    exact edge total."""
+    rs = np.random.RandomState(seed)
+    sizes = rs.randint(n_min, n_max + 1, size=n_graphs).astype(np.int64)
+    while sizes.sum() != total_nodes:
+        i = rs.randint(n_graphs)
+        step = 1 if sizes.sum() < total_nodes else -1
+        if n_min <= sizes[i] + step <= n_max:
+            sizes[i] += step
+    cand = []                                              # per graph: candidate pairs, bridge first
+    for n in sizes:
+        h = max(1, n // 2)
+        pairs = [(0, h)] if n > h else []
+        pairs += [(i, j) for i in range(n) for j in range(i + 1, n) if (i < h) == (j < h)]
+        cand.append(pairs)
+    want = np.minimum(np.rint(sizes * (total_edges / total_nodes)).astype(np.int64), [len(c) for c in cand])
+    while want.sum() != total_edges:
+        i = rs.randint(n_graphs)
+        step = 1 if want.sum() < total_edges else -1
+        if 0 <= want[i] + step <= len(cand[i]):
+            want[i] += step
+    mats = []
+    for n, pairs, k in zip(sizes, cand, want):
+        pick = [0] + list(1 + rs.choice(len(pairs) - 1, size=k - 1, replace=False)) if k > 0 and len(pairs) > 1 \
+            else ([0] if k > 0 else [])
+        r = [pairs[q][0] for q in pick] + [pairs[q][1] for q in pick]
+        c = [pairs[q][1] for q in pick] + [pairs[q][0] for q in pick]
+        mats.append(sp.csr_matrix((np.ones(len(r)), (r, c)), shape=(n, n)))
+    return mats, sizes
+
+
+def citation_graph(n=2708, m=2, seed=1432):
+    """Cora-shaped stand-in (config 4: the Planetoid download is unavailable offline): sparse
+    power-law graph with n nodes and ~2 m n stored entries (Cora: 2708 nodes, 10 556)."""
+    return power_law_graph(n, m, seed)

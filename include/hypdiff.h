@@ -187,6 +187,13 @@ int hd_feat_normalize(const void* x, int x_dtype, int64_t rows, int64_t dim, flo
  * workgroup in 8 fixed slices instead of by one lane group. */
 HD_DECL2(hd_spmm_csr, const int32_t* rowptr, const int32_t* col, const void* val, const void* x, void* out,
          int64_t rows, int64_t dim, const int32_t* long_rows, int64_t n_long, void* stream)
+/* the same on a column slab of wider matrices: x rows have pitch ldx, out rows pitch ldo (elements, >= dim;
+ * 16-byte loads when both are multiples of 4 (f32) / 2 (f64) and the bases are aligned).  A feature column's sum
+ * does not depend on the other columns, so spmm over column slabs == spmm over whole rows bit for bit: this is
+ * what lets a row-sharded HypAgg start on the first slab of the all-gathered tangent rows while the next slab is
+ * still on the wire (hypdiff_amd/dist.py). */
+HD_DECL2(hd_spmm_csr_strided, const int32_t* rowptr, const int32_t* col, const void* val, const void* x, int64_t ldx,
+         void* out, int64_t ldo, int64_t rows, int64_t dim, const int32_t* long_rows, int64_t n_long, void* stream)
 /* proj(expmap0(spmm(adj, xt))) :150-151, xt = logmap0(x) already in the tangent space (:134);
  * fuse_act != 0 appends HypAct.forward (:170-173) with (c_in, c_out, act) in the same pass */
 HD_DECL2(hd_pb_agg, const int32_t* rowptr, const int32_t* col, const void* val, const void* xt, void* out,

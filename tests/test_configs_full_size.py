@@ -1,0 +1,163 @@
+"""GPU: BASELINE.json's configurations at their OWN sizes against the oracle, under every fp32 GEMM
+kernel family (ops.GEMM_MODE = bf16x3 / exact / f16x2).
+
+  config 2 (the bench workload itself): Hyperboloid c=1 HGCN 21 -> 512 -> 512 on the 15 777-row
+            SynEgo1000-shaped set + one p_sample at D = 512, T = 1000
+            (models/encoders.py:115-119, models/direction_diffusion.py:272-291)
+  config 4: PoincareBall c=0.6 HGCN on a 2708-node citation-shaped graph, identity features (K = 2708
+            GEMM), D = 512
+  config 1: PoincareBall c=1 HGCN 14 -> 14 -> 14 on the 7 850-row SynCommunity1000-shaped set + p_sample
+            at D = 14, T = 200
+
+Bar: |got - oracle| <= 1e-5 |oracle| + 1e-6 * max|oracle| element by element (north_star's 1e-5 relative),
+widened per row only by the oracle's own fp32-vs-fp64 distance of that row (tests/conftest.py).  Every
+test prints its per-mode error table."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, err_stats
+from oracle import adjacency, diffusion as odiff, layers as olayers
+
+pytestmark = pytest.mark.gpu
+MODES = ["bf16x3", "exact", "f16x2"]
+
+
+def H(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture
+def gemm_mode(request):
+    from hypdiff_amd import ops
+    old, ops.GEMM_MODE = ops.GEMM_MODE, request.param
+    yield request.param
+    ops.GEMM_MODE = old
+
+
+ALL_MODES = pytest.mark.parametrize("gemm_mode", MODES, indirect=True)
+
+
+def _encoder(mname, c, feat_dim, dim, seed):
+    from hypdiff_amd.models.encoders import HGCN
+    args = types.SimpleNamespace(manifold=mname, c=c, cuda=0, device="cuda:0", feat_dim=feat_dim, dim=dim,
+                                 num_layers=2, act="relu", dropout=0.0, bias=0, use_att=0, local_agg=0)
+    torch.manual_seed(seed)
+    return HGCN(torch.tensor([c]).cuda(), args).cuda().eval()
+
+
+def _oracle_encode(mname, c, x, idx, val, shape, enc, dtype):
+    Ws = [l.linear.weight.detach().cpu().to(dtype) for l in enc.layers]
+    adj = (torch.from_numpy(idx), torch.from_numpy(val).to(dtype), shape)
+    return olayers.hgcn_encode(mname, x.to(dtype), adj, Ws, [c, c, c], prepend_time=False).numpy()
+
+
+def _oracle_p_sample(diff, img, t, labels, u0, T, dtype):
+    params = [(getattr(diff.mlp, f"fc{i}").weight.detach().cpu().to(dtype), getattr(diff.mlp, f"fc{i}").bias.detach().cpu().to(dtype))
+              for i in range(1, 6)]
+    if dtype == torch.float64:
+        # the same formulas with the denoiser evaluated in fp64: the conditioning yardstick
+        def mlp64(x, tt, p):
+            h = torch.cat((x.double(), tt.unsqueeze(1).double()), dim=1)
+            for i, (w, b) in enumerate(p):
+                h = torch.nn.functional.linear(h, w, b)
+                if i + 1 < len(p):
+                    h = torch.nn.functional.gelu(h)
+            return h
+        old, odiff.mlp_denoiser = odiff.mlp_denoiser, mlp64
+        try:
+            pred, x0 = odiff.p_sample(img, t, odiff.sign_table(u0), labels, odiff.schedule(T), params)
+        finally:
+            odiff.mlp_denoiser = old
+    else:
+        pred, x0 = odiff.p_sample(img, t, odiff.sign_table(u0), labels, odiff.schedule(T), params)
+    return pred.numpy(), x0.numpy()
+
+
+def _report(tag, mode, rows):
+    print(f"\n[{tag}] GEMM_MODE={mode}")
+    for name, got, want in rows:
+        mx, el = err_stats(got, want)
+        print(f"    {name:<28s} max-norm rel err {mx:.2e}   largest fraction of the plain bar (1e-5 |ref| + 1e-6 max|ref|) used: {el:.2f}")
+
+
+@ALL_MODES
+def test_config2_bench_workload_vs_oracle(gemm_mode):
+    """the workload bench.py times, compared element by element"""
+    import bench
+    w = bench.build_workload(512, 1000, 1432, "cuda:0")
+    host = w["host"]
+    with torch.no_grad():
+        h = w["enc"].encode(w["x"], w["adj"])
+        pred, x0 = w["diff"].p_sample(w["img"], None, 1, w["direction"], w["labels"], w["u0"], 500, None, True)
+        pred0, x00 = w["diff"].p_sample(w["img"], None, 1, w["direction"], w["labels"], w["u0"], 0, None, True)
+    want_h = _oracle_encode("Hyperboloid", 1.0, host["x"], host["idx"], host["val"], host["shape"], w["enc"], torch.float32)
+    ex_h = _oracle_encode("Hyperboloid", 1.0, host["x"], host["idx"], host["val"], host["shape"], w["enc"], torch.float64)
+    want_p, want_x0 = _oracle_p_sample(w["diff"], host["img"], 500, host["labels"], host["u0"], 1000, torch.float32)
+    ex_p, ex_x0 = _oracle_p_sample(w["diff"], host["img"], 500, host["labels"], host["u0"], 1000, torch.float64)
+    want_p0, want_x00 = _oracle_p_sample(w["diff"], host["img"], 0, host["labels"], host["u0"], 1000, torch.float32)
+    ex_p0, ex_x00 = _oracle_p_sample(w["diff"], host["img"], 0, host["labels"], host["u0"], 1000, torch.float64)
+    _report("config 2: 15 777 x 512", gemm_mode,
+            [("HGCN.encode (Hyperboloid)", H(h), want_h), ("p_sample t=500 x0", H(x0), want_x0),
+             ("p_sample t=500 pred", H(pred), want_p), ("p_sample t=0 x0", H(x00), want_x00),
+             ("p_sample t=0 pred", H(pred0), want_p0)])
+    assert h.shape == (15777, 512) and pred.dtype == torch.float64 and x0.dtype == torch.float32
+    assert_close(H(h), want_h, exact=ex_h, what="config 2 encode")
+    assert_close(H(x0), want_x0, exact=ex_x0, what="config 2 x0 (t=500)")
+    assert_close(H(pred), want_p, exact=ex_p, what="config 2 pred (t=500)")
+    assert_close(H(x00), want_x00, exact=ex_x00, what="config 2 x0 (t=0)")
+    assert_close(H(pred0), want_p0, exact=ex_p0, what="config 2 pred (t=0)")
+
+
+@ALL_MODES
+def test_config4_citation_encode_vs_oracle(gemm_mode):
+    """N = 2708, identity features -> the K = 2708 HypLinear GEMM (rows past the one-pass producers' limit),
+    D = 512, c = 0.6, PoincareBall; plus the link-prediction decoder on the embeddings."""
+    from hypdiff_amd import workloads
+    n, dim, c = 2708, 512, 0.6
+    adj = workloads.citation_graph(n)
+    idx, val, shape = adjacency.process_adj(adj)
+    x = torch.eye(n)
+    enc = _encoder("PoincareBall", c, n, dim, 11)
+    adj_t = torch.sparse_coo_tensor(torch.from_numpy(idx).cuda(), torch.from_numpy(val).cuda(), shape, check_invariants=False)
+    with torch.no_grad():
+        h = enc.encode(x.cuda(), adj_t)
+    want = _oracle_encode("PoincareBall", c, x, idx, val, shape, enc, torch.float32)
+    ex = _oracle_encode("PoincareBall", c, x, idx, val, shape, enc, torch.float64)
+    _report("config 4: 2708 x 2708 -> 512", gemm_mode, [("HGCN.encode (PoincareBall)", H(h), want)])
+    assert_close(H(h), want, exact=ex, what="config 4 encode")
+
+
+@ALL_MODES
+def test_config1_community_set_vs_oracle(gemm_mode):
+    """sum N = 7 850 rows, D = 14 (narrow rows: 4 / 16-lane groups, K = 15 first denoiser layer)"""
+    from hypdiff_amd import workloads
+    from hypdiff_amd.models.direction_diffusion import diffusion
+    mats, sizes = workloads.community_graph_set()
+    idx, val, shape, feats = workloads.batch_graph_set(mats, sizes, 14)
+    n, dim = shape[0], 14
+    assert n == 7850
+    enc = _encoder("PoincareBall", 1.0, 14, dim, 12)
+    x = torch.from_numpy(feats)
+    adj_t = torch.sparse_coo_tensor(torch.from_numpy(idx).cuda(), torch.from_numpy(val).cuda(), shape, check_invariants=False)
+    torch.manual_seed(13)
+    diff = diffusion(types.SimpleNamespace(r=2.0, t=1.0), dim, num_timesteps=200).eval()
+    rs = np.random.RandomState(3)
+    labels = rs.randint(0, 3, size=n).astype(np.int64)
+    u0 = torch.from_numpy((rs.standard_normal((3, dim)) * 0.05).astype(np.float32))
+    img = torch.from_numpy(rs.standard_normal((n, dim)))
+    with torch.no_grad():
+        h = enc.encode(x.cuda(), adj_t)
+        direction = diff.directions(u0.cuda())
+        pred, x0 = diff.p_sample(img.cuda(), None, 1, direction, labels, u0.cuda(), 100, None, True)
+    want_h = _oracle_encode("PoincareBall", 1.0, x, idx, val, shape, enc, torch.float32)
+    ex_h = _oracle_encode("PoincareBall", 1.0, x, idx, val, shape, enc, torch.float64)
+    want_p, want_x0 = _oracle_p_sample(diff, img, 100, labels, u0, 200, torch.float32)
+    ex_p, ex_x0 = _oracle_p_sample(diff, img, 100, labels, u0, 200, torch.float64)
+    _report("config 1: 7 850 x 14", gemm_mode, [("HGCN.encode (PoincareBall)", H(h), want_h),
+                                                 ("p_sample t=100 x0", H(x0), want_x0), ("p_sample t=100 pred", H(pred), want_p)])
+    assert_close(H(h), want_h, exact=ex_h, what="config 1 encode")
+    assert_close(H(x0), want_x0, exact=ex_x0, what="config 1 x0")
+    assert_close(H(pred), want_p, exact=ex_p, what="config 1 pred")

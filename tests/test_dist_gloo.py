@@ -59,6 +59,9 @@ def _worker(rank, world, port, q):
     spmm = lambda i, v, s, xx: olayers.spmm_coo(torch.from_numpy(i), torch.from_numpy(v), s, xx)
     out = sh.aggregate(xt[sh.lo:sh.hi], spmm)
     res["agg"] = torch.equal(out, full[sh.lo:sh.hi])
+    # ... and with the all-gather pipelined in column slabs (asynchronous collectives, one wait per slab)
+    out = sh.aggregate_slabs(xt[sh.lo:sh.hi], spmm, n_slabs=3)
+    res["agg_slabs"] = torch.equal(out, full[sh.lo:sh.hi])
     # (4) DataParallelTrainer: 3 Adam steps on equal shards == 3 full-batch Adam steps; ranks start
     #     from different weights (rank 0's are broadcast) and the gradients stay bucket views
     torch.manual_seed(100 + rank)
@@ -79,6 +82,21 @@ def _worker(rank, world, port, q):
     flat = tr.bucket.flat
     res["views"] = all(flat.data_ptr() <= p_.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4
                        for p_ in net.parameters())
+    # the same with the bucket cut into several chunks (sent from post-accumulate hooks while backward is
+    # still running) and with the single blocking all-reduce: identical weights either way
+    outs = []
+    for overlap, chunk in ((True, 64), (False, 4 << 20)):
+        torch.manual_seed(7)
+        n2 = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.GELU(), torch.nn.Linear(16, 8))
+        t2 = hdist.DataParallelTrainer(n2, lr=1e-2, overlap=overlap)
+        if overlap:
+            t2.bucket = hdist.GradBucket(n2.parameters(), chunk_bytes=chunk)
+            t2.opt = torch.optim.Adam(t2.bucket.params, lr=1e-2)
+            res["chunks"] = len(t2.bucket.chunks) >= 3
+        for _ in range(3):
+            t2.step(lambda: torch.nn.functional.mse_loss(n2(xb[lo:hi]), yb[lo:hi]))
+        outs.append([p_.detach().clone() for p_ in n2.parameters()])
+    res["overlap_equals_blocking"] = all(torch.equal(a, b) for a, b in zip(*outs))
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()

@@ -235,7 +235,10 @@ def test_hip_manifold_map_grads_vs_oracle(mname, c):
         # fp32 rounding of z 125-fold in the reference itself -> slack from its own fp64 evaluation
         x64 = torch.from_numpy(x_np).double().requires_grad_()
         (fn_ref(x64) * torch.from_numpy(Gm).double()).sum().backward()
-        assert_close(xh.grad.cpu(), xr.grad, what=what + " grad", exact=x64.grad.numpy(), **tol)
+        # (whole-array yardstick: every third row sits exactly ON the clip radius, where `norm > maxnorm`
+        # is decided by the rounding of the norm -- the reference's own fp32 and fp64 runs take different
+        # branches on some of those rows, and another summation order flips others)
+        assert_close(xh.grad.cpu(), xr.grad, what=what + " grad", exact=x64.grad.numpy(), exact_group="all", **tol)
 
     both(lambda x: man.proj(man.expmap0(man.proj_tan0(x, c), c), c),
          lambda x: M["proj"](M["expmap0"](M["proj_tan0"](x, c), c), c), u, "expmap0+proj")
