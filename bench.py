@@ -40,11 +40,13 @@ PEAK_NOTES = {"gemm_limbs": "dense bf16 MFMA peak 2500 TFLOP/s / 6 bf16 MFMAs pe
               "gemm_f32_bf16x3": "dense bf16 MFMA peak 2500 TFLOP/s / 6 bf16 MFMAs per algorithmic fp32 product",
               "gemm_f16x2": "dense fp16 MFMA peak 2500 TFLOP/s / 3 fp16 MFMAs per algorithmic fp32 product",
               "gemm_f32_mfma": "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"}
-DTYPES = {"exact": "f32",
-          "bf16x3": "f32 (GEMM operands carried as 3 bf16 limbs each, 6 exact limb products per fp32 product, "
-                    "fp32 accumulation)",
-          "f16x2": "f32 (denoiser GEMM operands carried as 2 row-scaled fp16 limbs each, 3 exact limb products per "
-                   "fp32 product, fp32 accumulation, error <= 3*2^-22 |a||w| per product; HypLinear GEMMs as 3 bf16 limbs)"}
+DTYPES = {"exact": "f32 (GEMMs on v_mfma_f32_32x32x2_f32: bit for bit an fmaf chain)",
+          "bf16x3": "f32 (fp32-faithful: every GEMM operand element split exactly into 3 bf16 limbs, 6 exact limb "
+                    "products per fp32 product accumulated in fp32, dropped terms < 2^-26 |a||w|; everything else "
+                    "plain fp32 / fp64 as in the reference)",
+          "f16x2": "f32 inputs/outputs, NARROWER-than-fp32 operands: inference GEMM operands (denoiser chain and "
+                   "HypLinear) carried as 2 fp16 limbs of the power-of-two-scaled ROW (22 bits relative to the row "
+                   "maximum), 3 exact limb products per fp32 product, fp32 accumulation"}
 
 
 def gemm_summary(events):
@@ -102,14 +104,15 @@ def build_workload(dim, T, seed, device):
     x = torch.from_numpy(feats).to(device)
     x = torch.cat([torch.zeros_like(x[:, :1]), x], dim=1).contiguous()     # base_models.py:79-81
     rs = np.random.RandomState(seed)
-    labels = rs.randint(0, 3, size=n).astype(np.int64)
+    labels = rs.randint(0, 3, size=n).astype(np.int64)                     # host array, as the reference holds it
     u0 = torch.from_numpy((rs.standard_normal((3, dim)) * 0.05).astype(np.float32)).to(device)
     img = torch.from_numpy(rs.standard_normal((n, dim))).to(device)        # fp64 state, as after step 1
     with torch.no_grad():
         direction = diff.directions(u0)
         ops.csr_of(adj)
+    labels_d = ops.labels_dev(labels, device)       # one upload, as p_sample_loop does for its T steps
     host = dict(idx=idx, val=val, shape=shape, x=x.cpu(), labels=labels, u0=u0.cpu(), img=img.cpu())
-    return dict(enc=enc, diff=diff, adj=adj, x=x, labels=labels, u0=u0, img=img, direction=direction, n=n,
+    return dict(enc=enc, diff=diff, adj=adj, x=x, labels=labels_d, u0=u0, img=img, direction=direction, n=n,
                 nnz=idx.shape[1], host=host, feat=feat + 1)
 
 
@@ -140,9 +143,14 @@ def one_step(w, t, ev=None):
     return h, pred
 
 
-def cpu_baseline(w, dim, T, budget_s=20.0):
-    """The oracle (CPU port of the reference path) on the same workload, host cores."""
-    from oracle import diffusion as odiff, layers as olayers
+def cpu_baseline(w, dim, T):
+    """The oracle (CPU restatement of the reference path) on the same workload, on the host cores
+    (BASELINE.md section 3 / SURVEY.md 8d): the vectorised port (`kind: "port"`) and the loop-faithful
+    form (`kind: "loop"`: tran_direction as the reference's per-row Python loop,
+    models/direction_diffusion.py:158-161 -- the only per-row loop inside encode + p_sample), each with
+    all host threads torch uses and with one thread; warm-ups + median of the timed steps,
+    time.perf_counter.  Bounded: the all-thread legs are 3 warm-ups + 10 steps, the 1-thread legs 1 + 3."""
+    from oracle import diffusion as odiff, layers as olayers, manifolds as om
     enc, diff, host = w["enc"], w["diff"], w["host"]
     Ws = [l.linear.weight.detach().cpu() for l in enc.layers]
     params = [(getattr(diff.mlp, f"fc{i}").weight.detach().cpu(), getattr(diff.mlp, f"fc{i}").bias.detach().cpu())
@@ -150,22 +158,35 @@ def cpu_baseline(w, dim, T, budget_s=20.0):
     adj = (torch.from_numpy(host["idx"]), torch.from_numpy(host["val"]), host["shape"])
     tables = odiff.schedule(T)
     signs = odiff.sign_table(host["u0"])
-    cores = torch.get_num_threads()
+    direction = list(om.pb_logmap0(host["u0"], 1.0).unbind(0))
+    all_threads = torch.get_num_threads()
 
-    def step(t):
+    def step(t, loop):
         olayers.hgcn_encode("Hyperboloid", host["x"], adj, Ws, [1.0, 1.0, 1.0], prepend_time=False)
-        odiff.p_sample(host["img"], t, signs, host["labels"], tables, params)
+        odiff.p_sample(host["img"], t, signs, host["labels"], tables, params, loop_direction=direction if loop else None)
 
-    with torch.no_grad():
-        step(T - 1)
-        n, t0 = 0, time.perf_counter()
-        while n < 30 and (time.perf_counter() - t0) < budget_s:
-            step(T - 2 - n)
-            n += 1
-        dt = time.perf_counter() - t0
-    return dict(value=w["n"] * n / dt, unit="node-steps/s", cores=cores, kind="port",
-                sample=f"{n} full steps of the same workload ({w['n']} rows) with the torch-CPU oracle, "
-                       f"{cores} threads, {dt:.1f} s")
+    def leg(kind, threads, warm, reps):
+        torch.set_num_threads(threads)
+        try:
+            with torch.no_grad():
+                for i in range(warm):
+                    step(T - 1 - i, kind == "loop")
+                ts = []
+                for i in range(reps):
+                    t0 = time.perf_counter()
+                    step(T - 1 - warm - i, kind == "loop")
+                    ts.append(time.perf_counter() - t0)
+        finally:
+            torch.set_num_threads(all_threads)
+        med = sorted(ts)[len(ts) // 2]
+        return dict(value=w["n"] / med, unit="node-steps/s", cores=threads, kind=kind, ms_per_step=med * 1e3,
+                    sample=f"{warm} warm-up + median of {reps} full steps of the same workload ({w['n']} rows), "
+                           f"{'loop-faithful (per-row tran_direction)' if kind == 'loop' else 'vectorised'} torch-CPU "
+                           f"oracle, {threads} thread{'s' if threads > 1 else ''}")
+
+    main = leg("port", all_threads, 3, 10)
+    main["others"] = [leg("loop", all_threads, 3, 10), leg("port", 1, 1, 3), leg("loop", 1, 1, 3)]
+    return main
 
 
 def train_leg(w, dim, device, steps, warmup, barrier, dist):
@@ -182,7 +203,7 @@ def train_leg(w, dim, device, steps, warmup, barrier, dist):
     if dist is not None:
         diff.sync_moments = True
     tr = DataParallelTrainer(diff.mlp, lr=1e-3)
-    loss_fn = lambda: diff(emb, None, w["labels"], w["u0"], restrict=True, graphset=True)
+    loss_fn = lambda: diff(emb, None, w["host"]["labels"], w["u0"], restrict=True, graphset=True)
     for _ in range(warmup):
         tr.step(loss_fn)
     barrier()
@@ -203,6 +224,49 @@ def train_leg(w, dim, device, steps, warmup, barrier, dist):
             "parallelism": "data-parallel x%d, one flat all-reduce per step" % world}
 
 
+def sharded_leg(device, rank, world, steps, warmup, barrier, dist):
+    """Secondary figure: config 5's path -- ONE power-law graph (Barabasi-Albert-like, m = 5, natural hubs
+    of ~10^4 neighbours) whose rows are split over the ranks, 125 000 rows per rank (weak scaling: 10^6
+    rows at 8 GPUs), features N(0, 0.1^2) of width 256, PoincareBall c = 0.6, HGCN 256 -> 256 -> 256.
+    Per layer the tangent block of every rank is all-gathered over RCCL in 4 column slabs, pipelined
+    against the local CSR SpMM (hypdiff_amd/dist.py).  value = rows of all ranks / wall time."""
+    from hypdiff_amd import dist as hdist, workloads
+    from hypdiff_amd.models.encoders import HGCN
+    rows_per_rank, d = 125_000, 256
+    n = rows_per_rank * world
+    adj = workloads.power_law_graph(n, 5, seed=1432)
+    big = workloads.normalize_adj(adj).tocoo()
+    idx = np.vstack((big.row, big.col)).astype(np.int64)
+    val = big.data.astype(np.float32)
+    sh = hdist.RowShardedAdj(idx, val, (n, n), rank, world)
+    rs = np.random.RandomState(100 + rank)
+    x = torch.from_numpy((rs.standard_normal((sh.hi - sh.lo, d)) * 0.1).astype(np.float32)).to(device)
+    args = types.SimpleNamespace(manifold="PoincareBall", c=0.6, cuda=0, device=device, feat_dim=d, dim=d,
+                                 num_layers=2, act="relu", dropout=0.0, bias=0, use_att=0, local_agg=0)
+    torch.manual_seed(1432)
+    enc = HGCN(torch.tensor([0.6], device=device), args).to(device).eval()
+    csr = hdist.shard_csr(sh, device)
+    with torch.no_grad():
+        for _ in range(warmup):
+            hdist.sharded_hgcn_encode(enc, x, sh)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            h = hdist.sharded_hgcn_encode(enc, x, sh)
+        barrier()
+        dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    nnz_loc = int(sh.local_values.shape[0])
+    return {"metric": "row-sharded HGCN encode nodes/s (config 5 shape)", "value": n * steps / dt, "unit": "nodes/s",
+            "steps": steps, "ms_per_step": dt / steps * 1e3, "rows_total": n, "rows_per_gpu": rows_per_rank, "dim": d,
+            "nnz_per_gpu": nnz_loc, "hub_rows_per_gpu": int(csr.n_long), "finite": bool(torch.isfinite(h).all()),
+            "allgather_bytes_per_layer_per_gpu": rows_per_rank * d * 4 * (world - 1),
+            "parallelism": "rows sharded x%d, tangent all-gather per layer in 4 column slabs overlapped with the SpMM" % world}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -215,11 +279,12 @@ def main():
                     help="skip the secondary leg that issues encode and p_sample on two HIP streams")
     ap.add_argument("--no-exact-leg", action="store_true", help="skip the comparison legs on the other fp32 GEMM kernels")
     ap.add_argument("--train-steps", type=int, default=20, help="steps of the secondary training leg (0 = skip)")
+    ap.add_argument("--sharded-steps", type=int, default=5, help="steps of the secondary row-sharded leg (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="headline steps only (profiling runs)")
     a = ap.parse_args()
     if a.no_secondary:
         a.no_overlap_leg = a.no_exact_leg = True
-        a.train_steps = 0
+        a.train_steps = a.sharded_steps = 0
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -255,14 +320,14 @@ def main():
     # HBM bytes per launch from the PMC passes of the same command (profiles/, collected with
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE; cannot be sampled from inside the process)
     traffic, traffic_src = None, None
-    tp = os.path.join(ROOT, "profiles", "r01_bench_hbm_traffic.json")
+    tp = os.path.join(ROOT, "profiles", "r02_bench_hbm_traffic.json")
     if os.path.exists(tp):
         try:
             ks = json.load(open(tp))["kernels"]
             hit = [v for k, v in ks.items() if k.startswith(GEMM_PMC_KEYS[dom])]
             if hit:
                 traffic = int(sum(v["hbm_bytes_corrected"] * v["launches"] for v in hit) / sum(v["launches"] for v in hit))
-                traffic_src = "profiles/r01_bench_hbm_traffic.json (rocprofv3 PMC, per-launch mean)"
+                traffic_src = "profiles/r02_bench_hbm_traffic.json (rocprofv3 PMC, per-launch mean)"
         except Exception:
             traffic = None
     gemm_ms = sum(v["ms"] for v in per.values())
@@ -292,7 +357,7 @@ def main():
                      "other_gemm_kernels": {k: {"launches": v["launches"], "TFLOP/s": v["flops"] / (v["ms"] * 1e-3) / 1e12,
                                                 "ms_per_step": v["ms"] / a.steps}
                                             for k, v in per.items() if k != dom},
-                     "memory_bound_kernels": "profiles/r01_kernel_roofline.jsonl (tools/bench_kernels.py)"},
+                     "memory_bound_kernels": "profiles/r02_kernel_roofline.jsonl (tools/bench_kernels.py)"},
     }
     enc_ms = sum(e[0].elapsed_time(e[1]) for e in phase) / max(1, len(phase))
     dif_ms = sum(e[1].elapsed_time(e[2]) for e in phase) / max(1, len(phase))
@@ -305,7 +370,7 @@ def main():
         mode = ops.GEMM_MODE
         out["other_gemm_modes"] = {}
         try:
-            for m2 in ("f16x2", "bf16x3", "exact"):
+            for m2 in ("bf16x3", "exact", "f16x2"):
                 if m2 == mode:
                     continue
                 ops.GEMM_MODE = m2
@@ -318,7 +383,7 @@ def main():
                     "value": rows_total / el2, "unit": "node-steps/s", "ms_per_step": el2 / a.steps * 1e3,
                     "roofline": {"bound": "mfma", "kernel": k2, "achieved": ach2, "peak": GEMM_PEAKS[k2],
                                  "unit": "TFLOP/s", "frac": ach2 / GEMM_PEAKS[k2]},
-                    "note": "same workload and steps with HD_GEMM_MODE=" + m2}
+                    "dtype": DTYPES[m2], "note": "same workload and steps with HD_GEMM_MODE=" + m2}
         finally:
             ops.GEMM_MODE = mode
     if not a.no_overlap_leg:
@@ -336,6 +401,11 @@ def main():
             out["train"] = train_leg(w, a.dim, device, a.train_steps, 3, barrier, dist)
         except Exception as e:                      # never lose the headline line to the secondary leg
             out["train"] = {"error": repr(e)}
+    if a.sharded_steps > 0:
+        try:
+            out["sharded"] = sharded_leg(device, rank, world, a.sharded_steps, 2, barrier, dist)
+        except Exception as e:
+            out["sharded"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w, a.dim, T)
     elif rank == 0:

@@ -49,9 +49,21 @@ def tran_direction_(noise, signs, labels):
     return noise
 
 
-def q_sample(x_start, t, noise, signs, labels, tables, restrict=False, c=1.0):
-    """:198-213.  Both branches of the reference return the same expression."""
-    if restrict:
+def tran_direction_loop_(noise, direction, labels):
+    """:154-163 the way the reference EXECUTES it: one Python iteration per row, each a sign(), a
+    row multiply and a row store.  Same values as tran_direction_; used by bench.py's loop-faithful
+    CPU baseline (`kind: "loop"`), where this loop is most of the reference's p_sample time."""
+    for i in range(noise.shape[0]):
+        noise[i] = noise[i] * torch.sign(direction[int(labels[i])])
+    return noise
+
+
+def q_sample(x_start, t, noise, signs, labels, tables, restrict=False, c=1.0, loop_direction=None):
+    """:198-213.  Both branches of the reference return the same expression.  loop_direction: the
+    list of direction vectors; when given, the sign flip runs as the reference's per-row loop."""
+    if restrict and loop_direction is not None:
+        tran_direction_loop_(noise, loop_direction, labels)
+    elif restrict:
         tran_direction_(noise, signs, labels)
     a = tables["sqrt_alphas_cumprod"].gather(-1, t).reshape(-1, 1)
     b = tables["sqrt_one_minus_alphas_cumprod"].gather(-1, t).reshape(-1, 1)
@@ -75,7 +87,7 @@ def mlp_denoiser(x, t, params):
     return h
 
 
-def p_sample(x, t, signs, labels, tables, params, c=1.0):
+def p_sample(x, t, signs, labels, tables, params, c=1.0, loop_direction=None):
     """:272-291 with graphset=True (mlp denoiser).  Returns (x_{t-1}, x0_hat)."""
     b = x.shape[0]
     tb = torch.full((b,), t, dtype=torch.long)
@@ -85,7 +97,7 @@ def p_sample(x, t, signs, labels, tables, params, c=1.0):
     eps = predict_noise_from_start(x, tb, x0, tables, c)
     x0.clamp_(-1.0, 1.0)
     t2 = torch.full((b,), t - 1 if t > 0 else 0, dtype=torch.long)
-    return q_sample(x0, t2, eps, signs, labels, tables, restrict=True, c=c), x0
+    return q_sample(x0, t2, eps, signs, labels, tables, restrict=True, c=c, loop_direction=loop_direction), x0
 
 
 def normalization(x):
