@@ -518,6 +518,120 @@ def capture_kmeans(out_dir):
     print("kmeans", len(store), "arrays")
 
 
+def capture_extras(out_dir):
+    """Rows f3 / f4 of SURVEY.md section 8 and the leftovers of a14 / a21: the HNN encoder
+    (models/encoders.py:48-71), the graph-VAE tail HNNLayer = HypLinear -> HypNorm -> HypAct of
+    models/hyp_layers.py:45-61,172-206,280-319 (PoincareBall, as models/hyp_model.py:19 builds it),
+    all seven outputs of utils.data_utils.mask_edges (:59-79), diff.generate's thresholding and
+    diff.decode_adj (diff.py:327-380), and diffusion.cal_u0 (models/direction_diffusion.py:130-139)."""
+    import scipy.sparse as sp
+    import manifolds
+    import models.hyp_layers as mhl
+    from models.encoders import HNN
+    from models.direction_diffusion import diffusion
+    from utils import data_utils
+    import diff as refdiff
+    store = {}
+    rs = np.random.RandomState(1432)
+    # (1) HNN.encode
+    n, feat, dim = 40, 12, 16
+    x0 = (rs.standard_normal((n, feat)) * 0.4).astype(np.float32)
+    store["hnn/x"] = x0
+    for mname, c in (("PoincareBall", 0.6), ("Hyperboloid", 1.0)):
+        x = T(x0)
+        if mname == "Hyperboloid":
+            x = torch.cat([torch.zeros_like(x)[:, 0:1], x], dim=1)
+        for bias in (0, 1):
+            args = lp_args(mname, c, n, x.shape[1], dim, bias)
+            torch.manual_seed(1432)
+            enc = HNN(torch.tensor([c]), args).eval()
+            if bias:
+                with torch.no_grad():
+                    for lyr in enc.layers:
+                        lyr.linear.bias.normal_(0, 0.1)
+            k = f"hnn/{mname}/bias{bias}/"
+            for i, lyr in enumerate(enc.layers):
+                store[k + f"W{i}"] = N(lyr.linear.weight)
+                store[k + f"b{i}"] = N(lyr.linear.bias)
+            with torch.no_grad():
+                store[k + "encode"] = N(enc.encode(x, None))
+    # (2) graph-VAE tail
+    pb = manifolds.PoincareBall()
+    for dt_name, tdt in (("f32", torch.float32), ("f64", torch.float64)):
+        for d_in, d_out in ((64, 64), (20, 36)):
+            torch.manual_seed(7)
+            lyr = mhl.HNNLayer(d_in, d_out, pb, pb).to(tdt).eval()
+            with torch.no_grad():
+                lyr.linear.bias.normal_(0, 0.2)
+                lyr.norm.norm.weight.uniform_(0.5, 1.5)
+                lyr.norm.norm.bias.normal_(0, 0.1)
+            k = f"vae/{dt_name}/{d_in}x{d_out}/"
+            store[k + "W"] = N(lyr.linear.linear.weight)
+            store[k + "bias"] = N(lyr.linear.bias)
+            store[k + "ln_w"] = N(lyr.norm.norm.weight)
+            store[k + "ln_b"] = N(lyr.norm.norm.bias)
+            for scale in (0.05, 1.0, 6.0):
+                xin = T((rs.standard_normal((30, d_in)) * scale)).to(tdt)
+                xin[0] = 0
+                store[k + f"s{scale:g}/x"] = N(xin)
+                with torch.no_grad():
+                    h1 = lyr.linear(xin)
+                    h2 = lyr.norm(h1.clone())
+                    store[k + f"s{scale:g}/linear"] = N(h1)
+                    store[k + f"s{scale:g}/norm"] = N(h2)
+                    store[k + f"s{scale:g}/act"] = N(lyr.hyp_act(h2))
+                    store[k + f"s{scale:g}/layer"] = N(lyr(xin))
+                    lyr.use_norm = False
+                    store[k + f"s{scale:g}/layer_nonorm"] = N(lyr(xin))
+                    lyr.use_norm = True
+    # (3) mask_edges, every output
+    for kind, n in (("citation", 300), ("ego", 17), ("ba", 100)):
+        adj = gi.synthetic_graph(kind, n)
+        out = data_utils.mask_edges(adj, 0.05, 0.1, 1432)
+        k = f"mask/{kind}{n}/"
+        store[k + "adj_train_indptr"] = out[0].tocsr().indptr.astype(np.int64)
+        store[k + "adj_train_indices"] = out[0].tocsr().indices.astype(np.int64)
+        for name, v in zip(("train_edges", "train_edges_false", "val_edges", "val_edges_false", "test_edges",
+                            "test_edges_false"), out[1:]):
+            store[k + name] = N(v)
+    # (4) decode_adj / generate
+    for (n, m) in ((9, 9), (12, 5), (1, 1), (6, 10)):
+        a = (rs.rand(n, m) > 0.5).astype(np.float64)
+        store[f"decode_adj/{n}x{m}/in"] = a
+        store[f"decode_adj/{n}x{m}/out"] = refdiff.decode_adj(a.copy())
+    g_n, mx = 6, 9
+    h = rs.rand(g_n, 1, mx, mx).astype(np.float32) * 0.98 + 0.01
+    h[2, 0] = 0.5                                          # constant graph: max == min -> nan -> no entry set
+    got = []
+    old_get, old_dump = refdiff.get_graph, refdiff.pickle.dump
+    refdiff.get_graph = lambda adj: adj
+    refdiff.pickle.dump = lambda obj, f: got.append(obj)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, "ds"))
+        os.environ["LOG_DIR"] = td
+        try:
+            refdiff.generate(types.SimpleNamespace(dataset="ds"), h, mx, ["fallback%d" % i for i in range(g_n)])
+        finally:
+            refdiff.get_graph, refdiff.pickle.dump = old_get, old_dump
+    store["generate/h"] = h
+    for i, gpred in enumerate(got[0]):
+        if isinstance(gpred, str):
+            store[f"generate/fallback{i}"] = np.array([1])
+        else:
+            store[f"generate/adj{i}"] = np.asarray(gpred)
+    # (5) cal_u0
+    dmod = diffusion(types.SimpleNamespace(r=2.0, t=1.0), 8)
+    data = [T((rs.standard_normal((m, 8)) * 0.2).astype(np.float32)) for m in (5, 1, 9)]
+    with torch.no_grad():
+        u = dmod.cal_u0(data)
+    for i, (d_, u_) in enumerate(zip(data, u)):
+        store[f"cal_u0/x{i}"] = N(d_)
+        store[f"cal_u0/u{i}"] = N(u_)
+    np.savez_compressed(os.path.join(out_dir, "extras.npz"), **store)
+    print("extras", len(store), "arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
@@ -539,6 +653,8 @@ def main():
         capture_ddpm(out)
     if a.only in ("", "train"):
         capture_train(out)
+    if a.only in ("", "extras"):
+        capture_extras(a.out)
     if a.only in ("", "kmeans"):
         capture_kmeans(out)
 
