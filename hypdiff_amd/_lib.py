@@ -42,6 +42,7 @@ SIGNATURES = {
     "hd_pb_logmap_at*": _at, "hd_pb_expmap_at*": _at, "hd_pb_sqdist*": _map2,
     "hd_pb_matvec_epilogue*": [P, P, P, I64, I64, HdCurv, c_int, P],
     "hd_pb_hyp_act*": _act,
+    "hd_pb_vae_hnn_tail*": [P, P, P, P, P, I64, I64, HdCurv, c_double, c_int, c_int, P],
     "hd_hb_proj*": _map1, "hd_hb_proj_tan0*": _map1, "hd_hb_expmap0*": _map1, "hd_hb_logmap0*": _map1,
     "hd_hb_expmap0_proj*": _map1, "hd_hb_sqdist*": _map2,
     "hd_hb_linear_epilogue*": [P, P, I64, I64, HdCurv, c_int, P],
@@ -98,6 +99,7 @@ SIGNATURES = {
     "hd_ddpm_noise": [P, P, P, P, I64, P, I64, I64, c_int, c_double, c_double, c_double, P],
     "hd_ddpm_step": [P, P, P, c_double, c_double, c_double, P, I64, P],
     "hd_embedding_add": [P, P, P, I64, I64, I64, P],
+    "hd_generate_adj_f32": [P, P, P, I64, I64, P],
     "hd_hkm_to_hyperboloid": [P, P, I64, I64, P],
     "hd_hkm_mean_step": [P, P, P, I64, I64, I64, c_double, P, P],
     "hd_hkm_to_poincare": [P, P, I64, I64, P],

@@ -234,6 +234,32 @@ struct Tile {
         }
         return group_sum<G>(f) > 0.f;
     }
+    // plain sum over the row (pad slots hold zeros)
+    __device__ __forceinline__ T sum() const {
+        T s = T(0);
+#pragma unroll
+        for (int k = 0; k < CHMAX; ++k) {
+            if (k < ch) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) s += v[k * VEC + e];
+            }
+        }
+        return group_sum<G>(s);
+    }
+    // v <- f(v, column) on the columns that exist; pad slots (column >= d) are reset to zero
+    template <class F>
+    __device__ __forceinline__ void map_cols(F f) {
+#pragma unroll
+        for (int k = 0; k < CHMAX; ++k) {
+            if (k < ch) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const int c = col(k, e);
+                    v[k * VEC + e] = c < d ? f(v[k * VEC + e], c) : T(0);
+                }
+            }
+        }
+    }
     template <class F>
     __device__ __forceinline__ void map(F f) {
 #pragma unroll

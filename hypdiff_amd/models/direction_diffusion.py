@@ -239,6 +239,14 @@ class diffusion(nn.Module):
             return val
         return d() if callable(d) else d
 
+    def cal_u0(self, data):
+        """:130-139: per cluster, expmap0(mean(logmap0(x))) (c = 1)"""
+        u = []
+        for x in data:
+            t = self.manifold.logmap0(x, c=1.0)
+            u.append(self.manifold.expmap0(torch.mean(t, dim=0, keepdim=True), c=1.0)[0])
+        return u
+
     def get_alphas2(self, timesteps):
         """:173-184; the tables for self.num_timesteps are cached instead of recomputed"""
         if timesteps == self.num_timesteps:

@@ -81,6 +81,14 @@ HD_DECL2(hd_pb_matvec_epilogue, const void* mx, const void* xnorm, void* out, in
 HD_DECL2(hd_pb_hyp_act, const void* x, void* out, int64_t rows, int64_t dim, hd_curv c_in, hd_curv c_out,
          int act, void* stream)
 
+/* Graph-VAE tail, models/hyp_layers.py:45-61 (HNNLayer = HypLinear :172-206 -> HypNorm :298-319 -> HypAct
+ * :280-296; Poincare ball, c = 1 in the reference) as ONE pass over mx = x @ W^T (rows, dim).  flags bit0:
+ * HypLinear's tail h = expmap0(mx), b = ptransp0(h, bias), h = expmap(u = h, p = b) (the reference's argument
+ * order); bit1: HypNorm h = expmap0(LayerNorm(logmap0(h))) with ln_w / ln_b (dim,) and eps; bit2: HypAct
+ * h = expmap0(act(logmap0(h))) (no proj).  bias (dim,) must be 16-byte aligned. */
+HD_DECL2(hd_pb_vae_hnn_tail, const void* mx, const void* bias, const void* ln_w, const void* ln_b, void* out,
+         int64_t rows, int64_t dim, hd_curv c, double eps, int flags, int act, void* stream)
+
 /* ---- Hyperboloid, manifolds/hyperboloid.py (column 0 = time coordinate) --------- */
 /* proj :43-52 */
 HD_DECL2(hd_hb_proj, const void* x, void* out, int64_t rows, int64_t dim, hd_curv c, void* stream)
@@ -361,6 +369,13 @@ int hd_ddpm_step(const float* x, const float* eps, const float* noise, double c1
 /* Backbone.forward ddpm.py:39-41: h[r] += table[idx[r]] in place */
 int hd_embedding_add(float* h, const float* table, const int64_t* idx, int64_t T, int64_t rows, int64_t dim,
                      void* stream);
+
+/* ---- latent -> graph decoding, diff.py:327-378 --------------------------------------------------
+ * The tensor part of generate (:334-349) and decode_adj (:355-378) for a set of graphs: h (n_graphs, n, n) fp32
+ * latents in (0, 1) -> logit -> per-graph min-max normalisation -> threshold 0.5 -> symmetric 0/1 adjacency
+ * adj (n_graphs, n+1, n+1) fp32; any[g] = 0 where nothing exceeds the threshold (the caller then keeps the input
+ * graph, :343-344).  The networkx hand-off (get_graph :380-391) stays on the host. */
+int hd_generate_adj_f32(const float* h, float* adj, int32_t* any, int64_t n_graphs, int64_t n, void* stream);
 
 /* ---- hyperbolic k-means (labels / centres u0 between encode and diffusion), fp64 -------------
  * hyperbolic_learning/hyperbolic_kmeans/hkmeans.py + util_hk.py.  Hyperboloid rows carry the
