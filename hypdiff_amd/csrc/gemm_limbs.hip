@@ -657,19 +657,29 @@ int gemm_impl(const char* who, const void* A, const void* W, const void* bias, c
     // workgroup's tiles stay on one XCD), unless K fits one slab.
     // Measured on the denoiser shapes (M = 15 777): bf16x3 'N' (two workgroups per CU), f16x2 'X' (two
     // workgroups = 16 wavefronts per CU; 64 KiB of LDS each).
-    char cfg = F16 ? 'X' : 'N';
-    if (const char* e = getenv(F16 ? "HD_GEMM_F16X2_TUNE" : "HD_GEMM_LIMBS_TUNE")) cfg = e[0];
-    static int n_cu = 0;
-    if (n_cu == 0) {
+    // tuning knobs and the CU count are read ONCE per process (HD_GEMM_TUNE_RELOAD=1 re-reads them on every
+    // launch: the tile-configuration sweeps of tools/bench_chain.py)
+    struct Knobs { char cfg_bf, cfg_f16; int persist, per_cu, n_cu, reload; };
+    static Knobs knobs = [] {
+        Knobs k{'N', 'X', 1, 0, 256, 0};
+        if (const char* e = getenv("HD_GEMM_LIMBS_TUNE")) k.cfg_bf = e[0];
+        if (const char* e = getenv("HD_GEMM_F16X2_TUNE")) k.cfg_f16 = e[0];
+        if (const char* e = getenv("HD_GEMM_LIMBS_PERSIST")) k.persist = atoi(e);
+        if (const char* e = getenv("HD_GEMM_LIMBS_PER_CU")) k.per_cu = atoi(e);
+        if (const char* e = getenv("HD_GEMM_TUNE_RELOAD")) k.reload = atoi(e);
         int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+            prop.multiProcessorCount > 0)
+            k.n_cu = prop.multiProcessorCount;
+        return k;
+    }();
+    if (knobs.reload) {
+        if (const char* e = getenv("HD_GEMM_LIMBS_TUNE")) knobs.cfg_bf = e[0];
+        if (const char* e = getenv("HD_GEMM_F16X2_TUNE")) knobs.cfg_f16 = e[0];
     }
-    int persist = 1, per_cu = 0;
-    if (const char* e = getenv("HD_GEMM_LIMBS_PERSIST")) persist = atoi(e);
-    if (const char* e = getenv("HD_GEMM_LIMBS_PER_CU")) per_cu = atoi(e);
+    const char cfg = F16 ? knobs.cfg_f16 : knobs.cfg_bf;
+    const int n_cu = knobs.n_cu, persist = knobs.persist, per_cu = knobs.per_cu;
 #define HD_LAUNCH(BNT_, WAVES_, PER_CU_)                                                                   \
     {                                                                                                      \
         const int tiles_n = (int)((N + BNT_ - 1) / BNT_);                                                  \

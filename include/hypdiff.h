@@ -50,7 +50,9 @@ size_t hd_last_error(char* buf, size_t cap);
 HD_DECL2(hd_pb_proj, const void* x, void* out, int64_t rows, int64_t dim, hd_curv c, void* stream)
 /* expmap0 :73-77 */
 HD_DECL2(hd_pb_expmap0, const void* u, void* out, int64_t rows, int64_t dim, hd_curv c, void* stream)
-/* logmap0 :79-83 (artanh in fp64, utils/math_utils.py:30-36) */
+/* logmap0 :79-83.  Artanh (utils/math_utils.py:30-36): fp64 rows evaluate the reference's literal fp64 formula;
+ * fp32 rows use the cancellation-free fp32 form 0.5 * log1p(2z / (1 - z)) -- the same values as the reference's
+ * fp64 detour to <= 4 fp32 ulp (golden vectors), without two software fp64 logs per row */
 HD_DECL2(hd_pb_logmap0, const void* p, void* out, int64_t rows, int64_t dim, hd_curv c, void* stream)
 /* proj(expmap0(proj_tan0(x))) -- the input lift of models/encoders.py:115-119 in one pass */
 HD_DECL2(hd_pb_expmap0_proj, const void* u, void* out, int64_t rows, int64_t dim, hd_curv c, void* stream)
@@ -96,7 +98,8 @@ HD_DECL2(hd_hb_proj, const void* x, void* out, int64_t rows, int64_t dim, hd_cur
 HD_DECL2(hd_hb_proj_tan0, const void* u, void* out, int64_t rows, int64_t dim, hd_curv c, void* stream)
 /* expmap0 :90-101 (includes its trailing proj) */
 HD_DECL2(hd_hb_expmap0, const void* u, void* out, int64_t rows, int64_t dim, hd_curv c, void* stream)
-/* logmap0 :103-113 (arcosh in fp64, utils/math_utils.py:57-63) */
+/* logmap0 :103-113.  Arcosh (utils/math_utils.py:57-63): literal fp64 formula for fp64 rows; fp32 rows use
+ * log1p((z - 1) + sqrt((z - 1)(z + 1))) in fp32 (<= 4 fp32 ulp from the reference's fp64 detour) */
 HD_DECL2(hd_hb_logmap0, const void* x, void* out, int64_t rows, int64_t dim, hd_curv c, void* stream)
 /* proj(expmap0(proj_tan0(x))) -- input lift, models/encoders.py:115-119 */
 HD_DECL2(hd_hb_expmap0_proj, const void* u, void* out, int64_t rows, int64_t dim, hd_curv c, void* stream)

@@ -7,6 +7,7 @@ import sys
 
 import torch
 
+os.environ["HD_GEMM_TUNE_RELOAD"] = "1"      # the library re-reads the tile configuration on every launch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hypdiff_amd import ops  # noqa: E402
 
