@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void limb_pack(const float* __restrict__ in, i
 //   PACK_NORM    x itself; also writes |x|_2 per row  manifolds/poincare.py:94-96
 enum PackMode { PACK_MLP = 0, PACK_HB_LOG0 = 1, PACK_NORM = 2 };
 constexpr int kPackChunks = 3;                                    // chunks per lane: cols <= 1536
-template <int MODE, typename TX>
+template <int MODE, typename TX, bool F16 = true>
 __global__ __launch_bounds__(256) void row_pack_f16x2(const TX* __restrict__ x, const void* __restrict__ t, int t_kind,
                                                       float t_scalar, int rows, int dim, int nslab, Curv cv,
                                                       uint4* __restrict__ out, int* __restrict__ ex,
@@ -273,32 +273,43 @@ __global__ __launch_bounds__(256) void row_pack_f16x2(const TX* __restrict__ x, 
             for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[it][q][e]));
 #pragma unroll
         for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-        const int e_row = exp_for(m, 15);
-        if (lane == 0 && row < rows) {
-            amax[row] = __float_as_uint(m);
-            ex[row] = e_row;
+        const int e_row = F16 ? exp_for(m, 15) : 0;
+        if constexpr (F16) {
+            if (lane == 0 && row < rows) {
+                amax[row] = __float_as_uint(m);
+                ex[row] = e_row;
+            }
         }
 #pragma unroll
         for (int q = 0; q < kPackChunks; ++q) {
             const int ch = lane + 64 * q;
             if (ch >= nchunk) continue;
-            uint2 h0, l0, h1, l1;
-            split4_f16(make_float4(ldexpf(v[it][q][0], e_row), ldexpf(v[it][q][1], e_row), ldexpf(v[it][q][2], e_row),
-                                   ldexpf(v[it][q][3], e_row)), h0, l0);
-            split4_f16(make_float4(ldexpf(v[it][q][4], e_row), ldexpf(v[it][q][5], e_row), ldexpf(v[it][q][6], e_row),
-                                   ldexpf(v[it][q][7], e_row)), h1, l1);
-            stage[ch * 17 + r16] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-            stage[(nchunk + ch) * 17 + r16] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            if constexpr (F16) {
+                uint2 h0, l0, h1, l1;
+                split4_f16(make_float4(ldexpf(v[it][q][0], e_row), ldexpf(v[it][q][1], e_row), ldexpf(v[it][q][2], e_row),
+                                       ldexpf(v[it][q][3], e_row)), h0, l0);
+                split4_f16(make_float4(ldexpf(v[it][q][4], e_row), ldexpf(v[it][q][5], e_row), ldexpf(v[it][q][6], e_row),
+                                       ldexpf(v[it][q][7], e_row)), h1, l1);
+                stage[ch * 17 + r16] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                stage[(nchunk + ch) * 17 + r16] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            } else {                                             // three bf16 limbs, no row scaling
+                uint2 h0, m0, l0, h1, m1, l1;
+                split4(make_float4(v[it][q][0], v[it][q][1], v[it][q][2], v[it][q][3]), h0, m0, l0);
+                split4(make_float4(v[it][q][4], v[it][q][5], v[it][q][6], v[it][q][7]), h1, m1, l1);
+                stage[ch * 17 + r16] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                stage[(nchunk + ch) * 17 + r16] = make_uint4(m0.x, m0.y, m1.x, m1.y);
+                stage[(2 * nchunk + ch) * 17 + r16] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            }
         }
     }
     __syncthreads();
     const int row16 = threadIdx.x & 15;
     const int64_t grow = (int64_t)blockIdx.x * 16 + row16;
     if (grow >= rows) return;
-    uint4* obase = out + (grow >> 7) * nslab * kTileOf<true> + (grow & 127);
-    for (int p = threadIdx.x >> 4; p < 2 * nchunk; p += 16) {
-        const int l = p >= nchunk, ch = p - l * nchunk;
-        obase[(int64_t)(ch >> 2) * kTileOf<true> + l * 4 * 128 + (ch & 3) * 128] = stage[p * 17 + row16];
+    uint4* obase = out + (grow >> 7) * nslab * kTileOf<F16> + (grow & 127);
+    for (int p = threadIdx.x >> 4; p < kLimbs<F16> * nchunk; p += 16) {
+        const int l = p / nchunk, ch = p - l * nchunk;
+        obase[(int64_t)(ch >> 2) * kTileOf<F16> + l * 4 * 128 + (ch & 3) * 128] = stage[p * 17 + row16];
     }
 }
 
@@ -768,6 +779,56 @@ extern "C" int hd_row_pack_f16x2_f32(const void* x, int mode, hd_curv c, void* o
             (const float*)x, nullptr, 2, 0.f, (int)rows, (int)dim, nslab, cv, (uint4*)out, (int*)ex, (unsigned*)amax,
             (float*)norms);
     return check_launch("hd_row_pack_f16x2_f32");
+}
+
+// the same one-pass producers for the bf16x3 format (three limbs, no row exponents): 48 B of LDS per element
+// of the 16-row stage, so rows of up to 1024 columns
+constexpr int kPackMaxBf16x3 = 1024;
+extern "C" int hd_mlp_pack_input_bf16x3(const void* x, int x_dtype, const void* t, int t_kind, double t_scalar,
+                                        void* out, int64_t rows, int64_t dim, void* st) {
+    HD_REQUIRE(rows >= 0 && dim >= 1 && dim + 1 <= kPackMaxBf16x3, "hd_mlp_pack_input_bf16x3: dim out of range (<= %d)",
+               kPackMaxBf16x3 - 1);
+    if (rows == 0) return HD_OK;
+    HD_REQUIRE(x && out && (t || t_kind == 2) && t_kind >= 0 && t_kind <= 2 && is_aligned16(out),
+               "hd_mlp_pack_input_bf16x3: bad argument");
+    HD_REQUIRE(rows < (1LL << 31), "hd_mlp_pack_input_bf16x3: size exceeds int32");
+    const int nslab = (int)((dim + 1 + 31) / 32);
+    const dim3 grid((unsigned)((rows + 15) / 16));
+    const size_t lds = (size_t)3 * nslab * 4 * 17 * sizeof(uint4);
+    if (int rc = x_dtype ? allow_lds(row_pack_f16x2<PACK_MLP, double, false>, lds, "hd_mlp_pack_input_bf16x3")
+                         : allow_lds(row_pack_f16x2<PACK_MLP, float, false>, lds, "hd_mlp_pack_input_bf16x3")) return rc;
+    if (x_dtype)
+        row_pack_f16x2<PACK_MLP, double, false><<<grid, 256, lds, (hipStream_t)st>>>(
+            (const double*)x, t, t_kind, (float)t_scalar, (int)rows, (int)dim, nslab, Curv{}, (uint4*)out, nullptr,
+            nullptr, nullptr);
+    else
+        row_pack_f16x2<PACK_MLP, float, false><<<grid, 256, lds, (hipStream_t)st>>>(
+            (const float*)x, t, t_kind, (float)t_scalar, (int)rows, (int)dim, nslab, Curv{}, (uint4*)out, nullptr,
+            nullptr, nullptr);
+    return check_launch("hd_mlp_pack_input_bf16x3");
+}
+
+extern "C" int hd_row_pack_bf16x3_f32(const void* x, int mode, hd_curv c, void* out, void* norms, int64_t rows,
+                                      int64_t dim, void* st) {
+    HD_REQUIRE(rows >= 0 && dim >= 1 && dim <= kPackMaxBf16x3, "hd_row_pack_bf16x3_f32: dim out of range (<= %d)",
+               kPackMaxBf16x3);
+    HD_REQUIRE(mode == PACK_HB_LOG0 || mode == PACK_NORM, "hd_row_pack_bf16x3_f32: mode must be 1 (hyperboloid logmap0) or 2 (rows + norms)");
+    if (rows == 0) return HD_OK;
+    HD_REQUIRE(x && out && is_aligned16(out) && (mode != PACK_NORM || norms), "hd_row_pack_bf16x3_f32: null or misaligned pointer");
+    HD_REQUIRE(rows < (1LL << 31), "hd_row_pack_bf16x3_f32: size exceeds int32");
+    const int nslab = (int)((dim + 31) / 32);
+    const dim3 grid((unsigned)((rows + 15) / 16));
+    const size_t lds = (size_t)3 * nslab * 4 * 17 * sizeof(uint4);
+    const Curv cv{c.c, c.sqrt_c, c.K, c.sqrt_K};
+    if (int rc = mode == PACK_HB_LOG0 ? allow_lds(row_pack_f16x2<PACK_HB_LOG0, float, false>, lds, "hd_row_pack_bf16x3_f32")
+                                      : allow_lds(row_pack_f16x2<PACK_NORM, float, false>, lds, "hd_row_pack_bf16x3_f32")) return rc;
+    if (mode == PACK_HB_LOG0)
+        row_pack_f16x2<PACK_HB_LOG0, float, false><<<grid, 256, lds, (hipStream_t)st>>>(
+            (const float*)x, nullptr, 2, 0.f, (int)rows, (int)dim, nslab, cv, (uint4*)out, nullptr, nullptr, nullptr);
+    else
+        row_pack_f16x2<PACK_NORM, float, false><<<grid, 256, lds, (hipStream_t)st>>>(
+            (const float*)x, nullptr, 2, 0.f, (int)rows, (int)dim, nslab, cv, (uint4*)out, nullptr, nullptr, (float*)norms);
+    return check_launch("hd_row_pack_bf16x3_f32");
 }
 
 extern "C" int hd_limb_unpack_f32(const void* in, int64_t rows, int64_t cols, void* out, int64_t ld, void* st) {

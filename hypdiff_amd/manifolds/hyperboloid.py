@@ -63,9 +63,10 @@ class Hyperboloid(Manifold):
             ops._lib.call("hd_hb_linear_smallk_f32", ops._p(x2), ops._p(ops.transposed_cached(m)), ops._p(out),
                           x2.shape[0], K, N, ops.curv(c), _flags, ops._stream())
             return out
-        if ops.use_f16x2(x2, m):
-            # logmap0 writes the f16x2 limb image of the GEMM operand directly (one pass over x)
-            mu, _ = ops.gemm_limbs(ops.row_pack(x2, 1, c), ops.weight_limbs(m, "f16x2")[0])
+        fmt = ops.limb_rows_fmt(x2, m)
+        if fmt:
+            # logmap0 writes the limb image of the GEMM operand directly (one pass over x)
+            mu, _ = ops.gemm_limbs(ops.row_pack(x2, 1, c, fmt), ops.weight_limbs(m, fmt)[0])
         else:
             mu = ops.gemm(ops.map1("hd_hb_logmap0", x2, c), m)
         out = torch.empty_like(mu)

@@ -58,9 +58,10 @@ class PoincareBall(Manifold):
         if m.dtype != x2.dtype:
             m = m.to(x2.dtype)
         m = ops.match_padded(x2, m)
-        if ops.use_f16x2(x2, m):
-            img, xn = ops.row_pack(x2, 2)       # row norms and the f16x2 operand image in one pass over x
-            mx, _ = ops.gemm_limbs(img, ops.weight_limbs(m, "f16x2")[0])
+        fmt = ops.limb_rows_fmt(x2, m)
+        if fmt:
+            img, xn = ops.row_pack(x2, 2, fmt=fmt)   # row norms and the operand's limb image in one pass over x
+            mx, _ = ops.gemm_limbs(img, ops.weight_limbs(m, fmt)[0])
         else:
             xn = ops.rownorm(x2)
             mx = ops.gemm(x2, m)

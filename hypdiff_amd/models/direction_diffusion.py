@@ -162,11 +162,16 @@ class mlp(nn.Module):
         chain = [(self.fc1.weight, self.fc1.bias, 1), (self.fc2.weight, self.fc2.bias, 1),
                  (self.fc3.weight, self.fc3.bias, 1), (self.fc4.weight, self.fc4.bias, 1),
                  (self.fc5.weight, self.fc5.bias, 0)]
-        if ops.GEMM_MODE == "f16x2" and d + 1 <= 1536 and not hag.wants_grad(*self.parameters()):
+        fmt = ops.GEMM_MODE if ops.GEMM_MODE in ops.ROW_PACK_MAX_DIM else None
+        if fmt and d + 1 <= ops.ROW_PACK_MAX_DIM[fmt] and n > 0 and not hag.wants_grad(*self.parameters()):
             # inference: the concat goes straight into the limb image of the first GEMM's operand
-            img = ops.limb_empty(n, d + 1, x.device, "f16x2", zero_amax=False)
-            ops._lib.call("hd_mlp_pack_input_f16x2", ops._p(x), 1 if x.dtype == torch.float64 else 0, ops._p(tp), kind,
-                          ts, ops._p(img.buf), ops._p(img.exp), ops._p(img.amax), n, d, ops._stream())
+            img = ops.limb_empty(n, d + 1, x.device, fmt, zero_amax=False)
+            if fmt == "f16x2":
+                ops._lib.call("hd_mlp_pack_input_f16x2", ops._p(x), 1 if x.dtype == torch.float64 else 0, ops._p(tp),
+                              kind, ts, ops._p(img.buf), ops._p(img.exp), ops._p(img.amax), n, d, ops._stream())
+            else:
+                ops._lib.call("hd_mlp_pack_input_bf16x3", ops._p(x), 1 if x.dtype == torch.float64 else 0, ops._p(tp),
+                              kind, ts, ops._p(img.buf), n, d, ops._stream())
             return ops.linear_chain(img, chain)
         h = torch.empty(n, ld, dtype=torch.float32, device=x.device)
         ops._lib.call("hd_mlp_pack_input", ops._p(x), 1 if x.dtype == torch.float64 else 0, ops._p(tp), kind, ts,

@@ -401,27 +401,34 @@ def gemm_limbs(a, w, bias=None, epi=0, resid=None, want_f32=True, want_limbs=Fal
     return c, cl
 
 
-ROW_PACK_MAX_DIM = 1536
+ROW_PACK_MAX_DIM = {"f16x2": 1536, "bf16x3": 1024}      # LDS stage of the one-pass row producers
 
 
-def row_pack(x2, mode, c=None):
-    """fp32 rows -> f16x2 LimbImage in one pass (hd_row_pack_f16x2_f32): mode 1 = Hyperboloid
-    logmap0(x, c), mode 2 = x itself (returns (image, row norms))."""
+def row_pack(x2, mode, c=None, fmt="f16x2"):
+    """fp32 rows -> LimbImage in one pass (hd_row_pack_f16x2_f32 / hd_row_pack_bf16x3_f32): mode 1 =
+    Hyperboloid logmap0(x, c), mode 2 = x itself (returns (image, row norms))."""
     _dev(x2)
-    assert x2.dim() == 2 and x2.dtype == torch.float32 and x2.is_contiguous() and x2.shape[1] <= ROW_PACK_MAX_DIM
+    assert x2.dim() == 2 and x2.dtype == torch.float32 and x2.is_contiguous() and x2.shape[1] <= ROW_PACK_MAX_DIM[fmt]
     n, d = x2.shape
-    img = limb_empty(n, d, x2.device, "f16x2", zero_amax=False)
+    img = limb_empty(n, d, x2.device, fmt, zero_amax=False)
     norms = torch.empty(n, dtype=torch.float32, device=x2.device) if mode == 2 else None
-    _lib.call("hd_row_pack_f16x2_f32", _p(x2), mode, curv(c if c is not None else 1.0), _p(img.buf), _p(img.exp),
-              _p(img.amax), _p(norms), n, d, _stream())
+    if fmt == "f16x2":
+        _lib.call("hd_row_pack_f16x2_f32", _p(x2), mode, curv(c if c is not None else 1.0), _p(img.buf), _p(img.exp),
+                  _p(img.amax), _p(norms), n, d, _stream())
+    else:
+        _lib.call("hd_row_pack_bf16x3_f32", _p(x2), mode, curv(c if c is not None else 1.0), _p(img.buf), _p(norms),
+                  n, d, _stream())
     return (img, norms) if mode == 2 else img
 
 
-def use_f16x2(x2, m):
-    """HypLinear's x @ W^T goes through the f16x2 limb kernel (inference, fp32, rows short enough
-    for the one-pass row producers)."""
-    return (GEMM_MODE == "f16x2" and x2.dtype == torch.float32 and m.dtype == torch.float32
-            and 128 <= x2.shape[1] <= ROW_PACK_MAX_DIM and x2.shape[0] > 0)      # narrower rows waste the 64-lane producer
+def limb_rows_fmt(x2, m):
+    """The limb format HypLinear's x @ W^T runs in (inference, fp32, rows short enough for the one-pass row
+    producers), or None for the plain GEMM of the fp32 rows."""
+    fmt = GEMM_MODE if GEMM_MODE in ROW_PACK_MAX_DIM else None
+    if (fmt and x2.dtype == torch.float32 and m.dtype == torch.float32 and x2.shape[0] > 0
+            and 128 <= x2.shape[1] <= ROW_PACK_MAX_DIM[fmt]):      # narrower rows waste the 64-lane producer
+        return fmt
+    return None
 
 
 def linear_chain(x, layers):

@@ -255,6 +255,15 @@ int hd_gemm_f32_bf16x3(const void* A, const void* W, const void* bias, const voi
 int64_t hd_limb_image_bytes(int64_t rows, int64_t cols);
 int hd_limb_pack_f32(const void* in, int64_t ld, int64_t rows, int64_t cols, void* out, void* stream);
 int hd_limb_unpack_f32(const void* in, int64_t rows, int64_t cols, void* out, int64_t ld, void* stream);
+/* One-pass producers of bf16x3 GEMM operands (no fp32 staging copy, one read of the rows): cat(x.float(),
+ * t[:,None]) of models/direction_diffusion.py:57-58 (x f32/f64 by x_dtype 0/1, t as in hd_mlp_pack_input;
+ * dim + 1 <= 1024), and the operands of HypLinear (dim <= 1024): mode 1 = Hyperboloid.logmap0(x, c)
+ * (manifolds/hyperboloid.py:103-113, operand of :122), mode 2 = x itself with norms[row] = |x|_2
+ * (manifolds/poincare.py:94-96). */
+int hd_mlp_pack_input_bf16x3(const void* x, int x_dtype, const void* t, int t_kind, double t_scalar, void* out,
+                             int64_t rows, int64_t dim, void* stream);
+int hd_row_pack_bf16x3_f32(const void* x, int mode, hd_curv c, void* out, void* norms, int64_t rows, int64_t dim,
+                           void* stream);
 int hd_gemm_limbs_f32(const void* A, const void* W, const void* bias, const void* resid, void* C, void* CL,
                       int64_t M, int64_t N, int64_t K, int64_t ldc, int epi, void* stream);
 /* ---- limb images of two row-scaled fp16 limbs ("f16x2"): half the matrix-core work ----

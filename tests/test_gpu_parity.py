@@ -584,6 +584,46 @@ def test_f16x2_limb_images_and_gemm():
         ops.GEMM_MODE = old
 
 
+def test_bf16x3_row_producers():
+    """hd_mlp_pack_input_bf16x3 == hd_mlp_pack_input followed by hd_limb_pack_f32, and hd_row_pack_bf16x3_f32 ==
+    the row kernel (logmap0 / identity + row norm) followed by hd_limb_pack_f32 -- both bit for bit (the whole
+    real rows out to the K padding of the last 32-column slab, which the GEMM multiplies and so must be zero)."""
+    from hypdiff_amd import ops
+    rs = np.random.RandomState(77)
+
+    def wide(im):
+        return ops.LimbImage(im.buf, im.rows, (im.cols + 31) // 32 * 32)
+    for d, dt in [(512, np.float64), (511, np.float64), (14, np.float32), (700, np.float32), (1023, np.float64)]:
+        n = 261
+        xx = (rs.standard_normal((n, d)) * np.exp(rs.standard_normal((n, 1)) * 3)).astype(dt)
+        for kind, tv in [(0, torch.from_numpy(rs.randint(0, 1000, size=n)).cuda()),
+                         (1, torch.from_numpy(rs.rand(n).astype(np.float32)).cuda()), (2, 37.0)]:
+            tp, ts = (tv, 0.0) if kind != 2 else (None, tv)
+            ld = (d + 1 + 3) // 4 * 4
+            hbuf = torch.empty(n, ld, dtype=torch.float32, device="cuda")
+            xg = G(xx)
+            ops._lib.call("hd_mlp_pack_input", ops._p(xg), int(dt == np.float64), ops._p(tp), kind, ts, ops._p(hbuf),
+                          n, d, ld, ops._stream())
+            want = ops.limb_pack(hbuf[:, : d + 1], "bf16x3")
+            img = ops.limb_empty(n, d + 1, "cuda", "bf16x3")
+            img.buf.fill_(0x55)                  # every byte of the image must be written by the producer
+            ops._lib.call("hd_mlp_pack_input_bf16x3", ops._p(xg), int(dt == np.float64), ops._p(tp), kind, ts,
+                          ops._p(img.buf), n, d, ops._stream())
+            assert np.array_equal(H(ops.limb_unpack(wide(img))), H(ops.limb_unpack(wide(want)))), (d, dt, kind)
+    for n, d in [(261, 512), (16, 128), (1000, 130), (77, 1024), (129, 36)]:
+        x = G((rs.standard_normal((n, d)) * 0.3).astype(np.float32))
+        x[:, 0] = torch.sqrt(1.0 / 0.7 + (x[:, 1:] ** 2).sum(1))        # on the hyperboloid of K = 1 / 0.7
+        img = ops.row_pack(x, 1, 0.7, "bf16x3")
+        want = ops.limb_pack(ops.map1("hd_hb_logmap0", x, 0.7), "bf16x3")
+        assert np.array_equal(H(ops.limb_unpack(wide(img))), H(ops.limb_unpack(wide(want)))), (n, d)
+        img, norms = ops.row_pack(x, 2, fmt="bf16x3")
+        assert np.array_equal(H(ops.limb_unpack(wide(img))), H(ops.limb_unpack(wide(ops.limb_pack(x, "bf16x3"))))), (n, d)
+        assert_close(H(norms), np.linalg.norm(H(x).astype(np.float64), axis=1), what="row norms", atol_scale=1e-6)
+    with pytest.raises(ValueError):
+        ops._lib.call("hd_row_pack_bf16x3_f32", None, 1, ops.curv(1.0), None, None, 4, 2000, ops._stream())
+    assert ops.row_pack(torch.zeros(0, 36, device="cuda"), 1, 1.0, "bf16x3").rows == 0
+
+
 @BOTH_GEMMS
 def test_mlp_and_p_sample_golden(golden, gemm_mode):
     g = golden("diffusion")
