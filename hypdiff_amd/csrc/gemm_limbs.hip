@@ -44,6 +44,7 @@
 // Replaces x @ W^T of manifolds/poincare.py:96, manifolds/hyperboloid.py:122 and nn.Linear +
 // F.gelu of models/direction_diffusion.py:56-69, ddpm.py:9-41.
 #include "hd_common.cuh"
+#include <type_traits>
 #include "hd_gelu.cuh"
 #include "hd_manifold.cuh"
 #include "../../include/hypdiff.h"
@@ -368,43 +369,46 @@ struct Scales {
 
 // epi: 0 none, 1 gelu, 2 resid + gelu (ddpm.py:20-22; bf16x3 only).  C (fp32 row-major, ldc) and CL
 // (limb image with nslab_out = ceil(N/32) slabs) are both optional outputs of the same values.
-// write-out of 4 consecutive columns nb..nb+3 of row m (tile-local row mloc): bias, epilogue, fp32
-// and limb stores; rmax collects max|x| of what was written (f16x2)
-template <bool F16>
+// write-out of 4 consecutive columns nb..nb+3 of row m (tile-local row mloc): v = accumulator + bias on
+// entry; epilogue, fp32 and limb stores; rmax collects max|x| of what was written (f16x2).
+// CHECK = false: interior tile, every column of the quad is < N (no per-element tests); vec = the fp32
+// rows of C / resid are 16-byte aligned at every quad (tile-uniform).
+template <bool F16, bool CHECK>
 __device__ __forceinline__ void store_quad(float v[4], int m, int mloc, int nb, int half, int N, int nout, int ldc,
-                                           int epi, const float* __restrict__ bias, const float* __restrict__ resid,
-                                           float* __restrict__ C, uint4* __restrict__ CL, size_t cl_tile_base,
-                                           int eo_m, float& rmax) {
-    {
-        float x[4], g[4];
+                                           int epi, bool vec, const float* __restrict__ resid, float* __restrict__ C,
+                                           uint4* __restrict__ CL, size_t cl_tile_base, int eo_m, float& rmax) {
+    if (epi != 0) {
+        float r[4] = {0.f, 0.f, 0.f, 0.f};
+        if (epi == 2) {
+            const float* rp = resid + (size_t)m * ldc + nb;
+            if (vec && (!CHECK || nb + 3 < N)) {
+                const float4 q = *reinterpret_cast<const float4*>(rp);
+                r[0] = q.x; r[1] = q.y; r[2] = q.z; r[3] = q.w;
+            } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) x[e] = v[e] + ((bias && nb + e < N) ? bias[nb + e] : 0.f);
-        if (epi != 0) {                                       // erf-GELU on the packed fp32 pipe, two at a time
-            const hd_f32x2 g01 = gelu_erf2(hd_f32x2{x[0], x[1]}), g23 = gelu_erf2(hd_f32x2{x[2], x[3]});
-            g[0] = g01.x; g[1] = g01.y; g[2] = g23.x; g[3] = g23.y;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int n = nb + e;
-            float y = 0.f;
-            if (n < N) {
-                y = epi == 0 ? x[e] : (epi == 1 ? g[e] : resid[(size_t)m * ldc + n] + g[e]);
-                if constexpr (F16) rmax = fmaxf(rmax, fabsf(y));
+                for (int e = 0; e < 4; ++e)
+                    if (!CHECK || nb + e < N) r[e] = rp[e];
             }
-            v[e] = y;
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = r[e] + gelu_erfc(v[e]);        // erf-GELU, single-polynomial erfc form
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (CHECK && nb + e >= N) v[e] = 0.f;
+        if constexpr (F16) rmax = fmaxf(rmax, fabsf(v[e]));
     }
     if (C) {
         float* o = C + (size_t)m * ldc + nb;
-        if (nb + 3 < N && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
+        if (vec && (!CHECK || nb + 3 < N)) {
             *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (nb + e < N) o[e] = v[e];
+                if (!CHECK || nb + e < N) o[e] = v[e];
         }
     }
-    if (CL && nb < nout) {
+    if (CL && (!CHECK || nb < nout)) {
         const int so = nb >> 5, kc = (nb & 31) >> 3;
         uint2* o = reinterpret_cast<uint2*>(CL + cl_tile_base + (size_t)so * kTileOf<F16> + kc * 128 + mloc) + half;
         if constexpr (F16) {
@@ -441,7 +445,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
                                                   const float* __restrict__ bias, const float* __restrict__ resid,
                                                   float* __restrict__ C, uint4* __restrict__ CL, int M, int N,
                                                   int nslab, int ldc, int epi, int tiles_m, int tiles_n,
-                                                  int nslab_out, Scales sc) {
+                                                  int nslab_out, Scales sc, int phase_mode, int delay_ticks) {
     constexpr int L = kLimbs<F16>, kTile = kTileOf<F16>;
     constexpr int WCN = WAVES / 2;               // wavefronts are laid out 2 (rows) x WCN (columns)
     constexpr int WCOLS = BNT / WCN;             // columns per wavefront: 32 or 64
@@ -480,6 +484,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
         }                                                                                   \
     }
     const int nout = nslab_out * 32;                      // limb image width: zeros from N up to here
+    // fp32 rows of C / resid: every 4-column quad is 16-byte aligned (quads start at multiples of 4)
+    const bool vec = (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(resid) & 15) == 0;
     // operand maps of v_mfma_f32_16x16x32: lane (r16 = lane&15, kq = lane>>4) supplies row r16,
     // k = 8 kq .. 8 kq + 7 of the slab = chunk kc = kq.  First operand = W rows (n), second = A rows
     // (m): the accumulator is the C^T tile, D column = lane&15 = m, D rows 4 kq + reg = n.
@@ -501,6 +508,32 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
     // flight; stores of a write-out issued in between only make the wait stricter -- and raw
     // barriers: __syncthreads would drain vmcnt to 0 (an LDS-DMA is a pending LDS write to the
     // compiler's fence).
+    if (phase_mode) {
+        // De-phasing: the workgroups that share a CU all start together and their tiles take the same
+        // time, so their write-outs (no MFMA work) would coincide for the whole launch.  The second
+        // workgroup of a CU starts half a tile late: one's write-out then runs under the other's K loop.
+        __shared__ int phase_s;
+        if (tid == 0) {
+            int ph;
+            const int g = gridDim.x, s_ = blockIdx.x;
+            const bool extra = s_ + (ntiles / g) * g < ntiles;      // this slot runs one tile more than the rest
+            if (phase_mode == 1) ph = 2 * (s_ >= g / 2);
+            else if (phase_mode == 2) ph = 2 * ((s_ >> 3) & 1);
+            else if (phase_mode == 5) ph = extra ? 0 : 2 * (s_ >= g / 2);
+            else if (phase_mode == 6) ph = extra ? 0 : 2 * (s_ >= g / 2) + ((s_ >> 3) & 1);
+            else if (phase_mode == 7) ph = extra ? 0 : (s_ >= g / 2 ? 2 : 0) + ((s_ >> 3) & 1) * (s_ >= g / 2 ? -1 : 1);
+            else {
+                const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, 32 bits
+                ph = 2 * (phase_mode == 3 ? (hw & 1) : ((hw >> 16) & 1));
+            }
+            phase_s = ph;
+        }
+        __syncthreads();
+        if (phase_s) {
+            const uint64_t t0 = wall_clock64(), wait = (uint64_t)delay_ticks * phase_s / 2;
+            while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+        }
+    }
     HD_STAGE(a_cur, w_cur, 0, 0)
     if (nslab > 1) HD_STAGE(a_cur, w_cur, 1, 1)
     for (;;) {
@@ -547,53 +580,62 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
                     acc[i][j] = c;
                 }
         }
-        // write-out of the C^T tile: a lane owns row m and 4 consecutive columns per accumulator
+        // write-out of the C^T tile: a lane owns row m and 4 consecutive columns per accumulator.  Interior
+        // tiles (every row < M, every column < N) take the copy without per-element tests.
         {
             const int m0 = tm * 128, n0 = tn * BNT;
-            const size_t cl_base = (size_t)tm * nslab_out * kTile;
-            int ewq[NT16][4];
-            if constexpr (F16) {
+            auto write_out = [&](auto check_c) {
+                constexpr bool CHECK = decltype(check_c)::value;
+                const size_t cl_base = (size_t)tm * nslab_out * kTile;
+                int ewq[NT16][4];
+                float bq[NT16][4];                                  // bias of this lane's columns, once per tile
 #pragma unroll
                 for (int j = 0; j < NT16; ++j)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int n = n0 + wc * WCOLS + j * 16 + 4 * kq + e;
-                        ewq[j][e] = n < N ? sc.ew[n] : 0;
+                        const int nc = CHECK ? (n < N ? n : N - 1) : n;
+                        bq[j][e] = bias ? bias[nc] : 0.f;
+                        if constexpr (F16) ewq[j][e] = sc.ew[nc];
                     }
-            }
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int mloc = wr * 64 + i * 16 + r16;
-                const int m = m0 + mloc;
-                if (m >= M) continue;
-                int ea_m = 0, eo_m = 0;
-                float rmax = 0.f;
-                if constexpr (F16) {
-                    ea_m = sc.ea[m];
-                    if (CL) {
-                        eo_m = exp_for(__uint_as_float(sc.amax_a[m]) * sc.bmul + sc.badd, 14);
-                        if (tn == 0 && wc == 0 && kq == 0) sc.eo[m] = eo_m;
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < NT16; ++j) {
-                    const int nb = n0 + wc * WCOLS + j * 16 + 4 * kq;
-                    if (nb >= nout && nb >= N) continue;
-                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                for (int i = 0; i < MT; ++i) {
+                    const int mloc = wr * 64 + i * 16 + r16;
+                    const int m = m0 + mloc;
+                    if (CHECK && m >= M) continue;
+                    int ea_m = 0, eo_m = 0;
+                    float rmax = 0.f;
                     if constexpr (F16) {
+                        ea_m = sc.ea[m];
+                        if (CL) {
+                            eo_m = exp_for(__uint_as_float(sc.amax_a[m]) * sc.bmul + sc.badd, 14);
+                            if (tn == 0 && wc == 0 && kq == 0) sc.eo[m] = eo_m;
+                        }
+                    }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = ldexpf(v[e], -(ea_m + ewq[j][e]));
+                    for (int j = 0; j < NT16; ++j) {
+                        const int nb = n0 + wc * WCOLS + j * 16 + 4 * kq;
+                        if (CHECK && nb >= nout && nb >= N) continue;
+                        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if constexpr (F16) v[e] = ldexpf(v[e], -(ea_m + ewq[j][e]));
+                            v[e] += bq[j][e];
+                        }
+                        store_quad<F16, CHECK>(v, m, mloc, nb, kq & 1, N, nout, ldc, epi, vec, resid, C, CL, cl_base,
+                                               eo_m, rmax);
                     }
-                    store_quad<F16>(v, m, mloc, nb, kq & 1, N, nout, ldc, epi, bias, resid, C, CL, cl_base, eo_m, rmax);
-                }
-                if constexpr (F16) {
-                    if (sc.amax_o) {                            // the 4 lanes of a row sit 16 apart
-                        rmax = fmaxf(rmax, __shfl_xor(rmax, 16));
-                        rmax = fmaxf(rmax, __shfl_xor(rmax, 32));
-                        if (kq == 0) atomicMax(&sc.amax_o[m], __float_as_uint(rmax));
+                    if constexpr (F16) {
+                        if (sc.amax_o) {                            // the 4 lanes of a row sit 16 apart
+                            rmax = fmaxf(rmax, __shfl_xor(rmax, 16));
+                            rmax = fmaxf(rmax, __shfl_xor(rmax, 32));
+                            if (kq == 0) atomicMax(&sc.amax_o[m], __float_as_uint(rmax));
+                        }
                     }
                 }
-            }
+            };
+            if (m0 + 128 <= M && n0 + BNT <= N) write_out(std::false_type{});
+            else write_out(std::true_type{});
         }
         if (!has_next) break;
         pb = (pb + nslab) & 1;
@@ -670,9 +712,11 @@ int gemm_impl(const char* who, const void* A, const void* W, const void* bias, c
     // workgroups = 16 wavefronts per CU; 64 KiB of LDS each).
     // tuning knobs and the CU count are read ONCE per process (HD_GEMM_TUNE_RELOAD=1 re-reads them on every
     // launch: the tile-configuration sweeps of tools/bench_chain.py)
-    struct Knobs { char cfg_bf, cfg_f16; int persist, per_cu, n_cu, reload; };
+    struct Knobs { char cfg_bf, cfg_f16; int persist, per_cu, n_cu, reload, phase, delay_ns; };
     static Knobs knobs = [] {
-        Knobs k{'N', 'X', 1, 0, 256, 0};
+        Knobs k{'N', 'X', 1, 0, 256, 0, 7, 500};
+        if (const char* e = getenv("HD_GEMM_LIMBS_PHASE")) k.phase = atoi(e);
+        if (const char* e = getenv("HD_GEMM_LIMBS_DELAY_NS")) k.delay_ns = atoi(e);
         if (const char* e = getenv("HD_GEMM_LIMBS_TUNE")) k.cfg_bf = e[0];
         if (const char* e = getenv("HD_GEMM_F16X2_TUNE")) k.cfg_f16 = e[0];
         if (const char* e = getenv("HD_GEMM_LIMBS_PERSIST")) k.persist = atoi(e);
@@ -688,6 +732,8 @@ int gemm_impl(const char* who, const void* A, const void* W, const void* bias, c
     if (knobs.reload) {
         if (const char* e = getenv("HD_GEMM_LIMBS_TUNE")) knobs.cfg_bf = e[0];
         if (const char* e = getenv("HD_GEMM_F16X2_TUNE")) knobs.cfg_f16 = e[0];
+        if (const char* e = getenv("HD_GEMM_LIMBS_PHASE")) knobs.phase = atoi(e);
+        if (const char* e = getenv("HD_GEMM_LIMBS_DELAY_NS")) knobs.delay_ns = atoi(e);
     }
     const char cfg = F16 ? knobs.cfg_f16 : knobs.cfg_bf;
     const int n_cu = knobs.n_cu, persist = knobs.persist, per_cu = knobs.per_cu;
@@ -701,7 +747,8 @@ int gemm_impl(const char* who, const void* A, const void* W, const void* bias, c
         if (persist && nslab >= 2 && resident >= 8 && grid > resident) grid = resident;                    \
         gemm_limbs<BNT_, WAVES_, F16><<<dim3((unsigned)grid), dim3(WAVES_ * 64), 0, (hipStream_t)st>>>(    \
             (const uint4*)A, (const uint4*)W, (const float*)bias, (const float*)resid, (float*)C, (uint4*)CL,  \
-            (int)M, (int)N, nslab, (int)ldc, epi, tiles_m, tiles_n, nslab_out, sc);                        \
+            (int)M, (int)N, nslab, (int)ldc, epi, tiles_m, tiles_n, nslab_out, sc,                         \
+            grid < ntiles ? knobs.phase : 0, (int)((int64_t)knobs.delay_ns * nslab / 10));                 \
     }
     if (cfg == 'W') HD_LAUNCH(128, 4, (F16 ? 2 : 1))
     else if (cfg == 'X') HD_LAUNCH(128, 8, (F16 ? 2 : 1))

@@ -615,11 +615,14 @@ def test_bf16x3_row_producers():
         x[:, 0] = torch.sqrt(1.0 / 0.7 + (x[:, 1:] ** 2).sum(1))        # on the hyperboloid of K = 1 / 0.7
         img = ops.row_pack(x, 1, 0.7, "bf16x3")
         want = ops.limb_pack(ops.map1("hd_hb_logmap0", x, 0.7), "bf16x3")
-        assert np.array_equal(H(ops.limb_unpack(wide(img))), H(ops.limb_unpack(wide(want)))), (n, d)
+        # (64 lanes per row here, 4 / 16 in the generic row kernel: the row reduction rounds differently)
+        got_rows, want_rows = H(ops.limb_unpack(wide(img))), H(ops.limb_unpack(wide(want)))
+        assert np.array_equal(got_rows[:, d:], want_rows[:, d:]) and not got_rows[:, d:].any()
+        assert_close(got_rows, want_rows, what="logmap0 rows as bf16x3 limbs", rtol=4e-7, atol_scale=0)
         img, norms = ops.row_pack(x, 2, fmt="bf16x3")
         assert np.array_equal(H(ops.limb_unpack(wide(img))), H(ops.limb_unpack(wide(ops.limb_pack(x, "bf16x3"))))), (n, d)
         assert_close(H(norms), np.linalg.norm(H(x).astype(np.float64), axis=1), what="row norms", atol_scale=1e-6)
-    with pytest.raises(ValueError):
+    with pytest.raises(RuntimeError, match="dim out of range"):
         ops._lib.call("hd_row_pack_bf16x3_f32", None, 1, ops.curv(1.0), None, None, 4, 2000, ops._stream())
     assert ops.row_pack(torch.zeros(0, 36, device="cuda"), 1, 1.0, "bf16x3").rows == 0
 

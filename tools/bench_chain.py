@@ -30,13 +30,17 @@ def main():
     ap.add_argument("--fmt", default="bf16x3")
     ap.add_argument("--tunes", default="N,W,X")
     ap.add_argument("--rows", type=int, default=15777)
+    ap.add_argument("--phase", default="0", help="HD_GEMM_LIMBS_PHASE values, comma separated")
+    ap.add_argument("--delay", default="500", help="HD_GEMM_LIMBS_DELAY_NS values (ns per K slab), comma separated")
     a = ap.parse_args()
     M = a.rows
     dims = [513, 800, 900, 800, 700, 512]
     torch.manual_seed(0)
     env = "HD_GEMM_LIMBS_TUNE" if a.fmt == "bf16x3" else "HD_GEMM_F16X2_TUNE"
-    for tune in a.tunes.split(","):
+    for tune, phase, delay in [(t, p, d) for t in a.tunes.split(",") for p in a.phase.split(",")
+                               for d in (a.delay.split(",") if p != "0" else ["0"])]:
         os.environ[env] = tune
+        os.environ["HD_GEMM_LIMBS_PHASE"], os.environ["HD_GEMM_LIMBS_DELAY_NS"] = phase, delay
         tot, flops = 0.0, 0.0
         line = []
         for l in range(5):
@@ -51,7 +55,7 @@ def main():
             tot += t
             flops += 2.0 * M * N * K
             line.append(f"L{l + 1} {t:6.1f} us {2.0 * M * N * K / t / 1e6:5.0f} TF")
-        print(f"{a.fmt} tune={tune}: " + " | ".join(line) + f" || chain {tot:6.1f} us {flops / tot / 1e6:5.0f} TF", flush=True)
+        print(f"{a.fmt} tune={tune} phase={phase} delay={delay}: " + " | ".join(line) + f" || chain {tot:6.1f} us {flops / tot / 1e6:5.0f} TF", flush=True)
 
 
 if __name__ == "__main__":

@@ -14,9 +14,9 @@ def timeit(fn, iters=30):
     return e0.elapsed_time(e1) / iters * 1e3
 
 fmt = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
-M = 15777
-for N in (768, 800, 512):
-    for K in (32, 64, 128, 256, 512, 1024, 2048):
+M = int(os.environ.get("KSWEEP_M", 15777))
+for N in [int(v) for v in os.environ.get("KSWEEP_N", "768,800,512").split(",")]:
+    for K in [int(v) for v in os.environ.get("KSWEEP_K", "32,64,128,256,512,1024,2048").split(",")]:
         a = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.randn(N, device="cuda")
         al, wl = ops.limb_pack(a, fmt), ops.limb_pack(w, fmt)
         t0 = timeit(lambda: ops.gemm_limbs(al, wl, None, epi=0, want_f32=True))
