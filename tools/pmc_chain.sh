@@ -1,0 +1,18 @@
+#!/bin/bash
+# L2-miss (fabric) read traffic of the denoiser chain's GEMMs per tile configuration: tools/pmc_chain.sh <tunes>
+cd /tmp && export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_chain
+rm -rf $OUT; mkdir -p $OUT
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/tools/bench_chain.py --tunes $1 > $OUT/log.txt 2>&1 || { tail -20 $OUT/log.txt; exit 1; }
+python3 - <<PY
+import csv, glob, collections
+acc = collections.defaultdict(lambda: [0, 0.0])
+for f in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == "FETCH_SIZE" and "gemm_limbs" in r["Kernel_Name"]:
+            k = r["Kernel_Name"].split("(")[1] if False else r["Kernel_Name"][:70]
+            g = (k, r.get("Grid_Size", ""), r.get("LDS_Block_Size", ""))
+            acc[k][0] += 1; acc[k][1] += float(r["Counter_Value"])
+for k, (n, v) in acc.items():
+    print(f"{k}: launches {n}, mean FETCH_SIZE {v / n / 1024:.1f} MiB (x2 corrected {2 * v / n / 1024:.1f} MiB)")
+PY
