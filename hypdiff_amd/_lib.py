@@ -33,6 +33,7 @@ SIZE_QUERIES = {
     "hd_hkm_workspace_doubles": [I64, I64, I64],
     "hd_limb_image_bytes": [I64, I64],
     "hd_limb_image_bytes_f16x2": [I64, I64],
+    "hd_smallk_image_bytes": [I64],
 }
 
 # name -> argtypes; names ending in "*" exist as _f32 and _f64
@@ -62,6 +63,8 @@ SIGNATURES = {
     "hd_hb_edge_decode_bwd*": [P, P, I64, P, P, I64, I64, HdCurv, c_int, c_double, c_double, P],
     "hd_hb_linear_tail_rows_f32": [P, P, I64, I64, HdCurv, c_int, P],
     "hd_hb_linear_smallk_f32": [P, P, P, I64, I64, I64, HdCurv, c_int, P],
+    "hd_smallk_pack_w_f32": [P, I64, I64, I64, P, P],
+    "hd_hb_linear_smallk_bf16x3_f32": [P, P, P, I64, I64, I64, HdCurv, c_int, P],
     "hd_csr_from_coo": [P, P, I64, I64, I64, P, P, P, P],
     "hd_adj_count": [P, P, I64, P, P, P],
     "hd_adj_fill": [P, P, P, I64, P, c_int, P, P, P, P],

@@ -2,6 +2,7 @@
 // Memory-bound kernels: every row is read once and written once; all norms, clamps,
 // artanh/arcosh and rescales of a composite map happen in registers in between.
 #include "hd_rowkernels.cuh"
+#include "hd_limbs.cuh"
 #include <stdlib.h>
 #include "../../include/hypdiff.h"
 
@@ -315,6 +316,104 @@ __global__ __launch_bounds__(WAVES * 64) void hb_linear_smallk(const float* __re
     }
 }
 
+// The same fused layer on the matrix cores (GEMM_MODE bf16x3 / f16x2): with K <= 32 the contraction is ONE
+// k-step of v_mfma_f32_16x16x32_bf16 per 16x16 output tile and limb pair (6 per tile: fp32-faithful, dropped
+// terms < 2^-26 |u||w|), ~1.3 us of matrix time for 15 777 x 21 -> 512 against ~5 us of fp32 FMAs.  A wavefront
+// owns 16 rows: lane (r16, kq) reads x[row r16][8 kq .. 8 kq + 7], takes logmap0 (4 lanes per row, two
+// shuffles), splits u into three bf16 limbs in registers -- the A operand never touches memory -- and multiplies
+// it with the pre-split W image (hd_smallk_pack_w_f32: [n-tile][limb][lane] uint4, staged once per workgroup
+// into LDS by LDS-DMA).  The accumulators hold row r16, columns 16 jt + 4 kq .. + 3: the row tail reduces over
+// them with two shuffles and the result is written as float4s.
+template <int NT>
+__global__ __launch_bounds__(256) void hb_linear_smallk_mfma(const float* __restrict__ x, const uint4* __restrict__ Wimg,
+                                                             float* __restrict__ out, int64_t n, int K, int N,
+                                                             Curv cv, int flags) {
+    extern __shared__ uint4 wl[];                            // [jt][limb][lane]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int nt = N >> 4;
+    for (int p = wave; p < nt * 3; p += 4) limb_glds16(Wimg + p * 64 + lane, wl + p * 64);
+    const int64_t row_raw = ((int64_t)blockIdx.x * 4 + wave) * 16 + r16;
+    const int64_t row = row_raw < n ? row_raw : n - 1;
+    const float sK = (float)cv.sK;
+    float xv[8], ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 8 * kq + e;
+        xv[e] = k < K ? x[row * K + k] : 0.f;
+        if (k >= 1) ss = fmaf(xv[e], xv[e], ss);             // hyperboloid.py:105-106
+    }
+    ss += __shfl_xor(ss, 16);
+    ss += __shfl_xor(ss, 32);
+    const float x0 = __shfl(xv[0], r16);                     // time coordinate: lane (r16, kq = 0)
+    uint4 ua[3];
+    {                                                        // logmap0 (hyperboloid.py:103-113)
+        const float nrm = clamp_min(hd_sqrt(ss), (float)kMinNorm);
+        const float theta = clamp_min(x0 / sK, (float)(1.0 + Lim<float>::hb_eps));
+        const float f = sK * arcosh_ref(theta) / nrm;
+        float u[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) u[e] = (8 * kq + e == 0) ? 0.f : xv[e] * f;
+        limb_split8(u, ua[0], ua[1], ua[2]);
+    }
+    lf32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = lf32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // operand maps of v_mfma_f32_16x16x32: first operand = W rows (n = 16 jt + r16), second = u rows (m = r16),
+    // k = 8 kq .. 8 kq + 7; D column = lane & 15 = m, D rows 4 kq + reg = n
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        if (j < nt) {
+            const uint4 w0 = wl[(j * 3 + 0) * 64 + lane], w1 = wl[(j * 3 + 1) * 64 + lane], w2 = wl[(j * 3 + 2) * 64 + lane];
+            lf32x4 c = acc[j];
+#define HD_MM(wv, av) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lbf16x8, wv), \
+                                                          __builtin_bit_cast(lbf16x8, av), c, 0, 0, 0);
+            HD_MM(w0, ua[2]) HD_MM(w2, ua[0]) HD_MM(w1, ua[1]) HD_MM(w0, ua[1]) HD_MM(w1, ua[0]) HD_MM(w0, ua[0])
+#undef HD_MM
+            acc[j] = c;
+        }
+    }
+    float s2 = 0.f;                                          // spatial |mu|^2 of row r16 (column 0 excluded)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (!(j == 0 && r == 0)) s2 = fmaf(acc[j][r], acc[j][r], s2);
+    if (kq != 0) s2 = fmaf(acc[0][0], acc[0][0], s2);
+    s2 += __shfl_xor(s2, 16);
+    s2 += __shfl_xor(s2, 32);
+    float f2, t0;
+    hb_linear_tail_scalars(s2, flags, cv, f2, t0);           // expmap0 (-> proj) (-> logmap0)
+    if (row_raw >= n) return;
+    float* o = out + row * N + 4 * kq;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        if (j < nt) {
+            float4 v = make_float4(acc[j][0] * f2, acc[j][1] * f2, acc[j][2] * f2, acc[j][3] * f2);
+            if (j == 0 && kq == 0) v.x = t0;
+            *reinterpret_cast<float4*>(o + 16 * j) = v;
+        }
+    }
+}
+
+// W (N, K) fp32 row-major (row stride ld) -> the operand image of hb_linear_smallk_mfma: uint4 index
+// (jt * 3 + limb) * 64 + lane holds limb `limb` of W[16 jt + (lane & 15)][8 (lane >> 4) .. + 7], zero for k >= K
+__global__ __launch_bounds__(64) void smallk_pack_w(const float* __restrict__ W, int64_t ld, int N, int K,
+                                                    uint4* __restrict__ img) {
+    const int jt = blockIdx.x, lane = threadIdx.x;
+    const int nrow = 16 * jt + (lane & 15), k0 = 8 * (lane >> 4);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (nrow < N && k0 + e < K) ? W[(int64_t)nrow * ld + k0 + e] : 0.f;
+    uint4 h, m, l;
+    limb_split8(v, h, m, l);
+    img[(jt * 3 + 0) * 64 + lane] = h;
+    img[(jt * 3 + 1) * 64 + lane] = m;
+    img[(jt * 3 + 2) * 64 + lane] = l;
+}
+
 // hd_hb_linear_epilogue for fp32 rows of up to 512 columns: four rows per wavefront, scalar chain once
 template <int R>
 __global__ __launch_bounds__(256) void hb_linear_tail_rows(const float* __restrict__ mu, float* __restrict__ out,
@@ -358,6 +457,46 @@ extern "C" int hd_hb_linear_tail_rows_f32(const void* mu, void* out, int64_t n, 
     hb_linear_tail_rows<4><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)st>>>((const float*)mu, (float*)out, n,
                                                                                       (int)d, mk(c), flags);
     return check_launch("hd_hb_linear_tail_rows_f32");
+}
+
+extern "C" int64_t hd_smallk_image_bytes(int64_t d_out) { return d_out < 1 ? -1 : (d_out + 15) / 16 * 3 * 64 * 16; }
+
+extern "C" int hd_smallk_pack_w_f32(const void* W, int64_t ld, int64_t d_out, int64_t d_in, void* img, void* st) {
+    HD_REQUIRE(d_out >= 1 && d_in >= 1 && d_in <= 32 && ld >= d_in, "hd_smallk_pack_w_f32: d_in must be <= 32");
+    HD_REQUIRE(W && img && is_aligned16(img), "hd_smallk_pack_w_f32: null or misaligned pointer");
+    HD_REQUIRE(d_out < (1LL << 24), "hd_smallk_pack_w_f32: d_out too large");
+    smallk_pack_w<<<dim3((unsigned)((d_out + 15) / 16)), dim3(64), 0, (hipStream_t)st>>>(
+        (const float*)W, ld, (int)d_out, (int)d_in, (uint4*)img);
+    return check_launch("hd_smallk_pack_w_f32");
+}
+
+extern "C" int hd_hb_linear_smallk_bf16x3_f32(const void* x, const void* Wimg, void* out, int64_t rows, int64_t d_in,
+                                              int64_t d_out, hd_curv c, int flags, void* st) {
+    HD_REQUIRE(rows >= 0 && d_in >= 1 && d_in <= 32 && d_out >= 16 && d_out <= 512 && d_out % 16 == 0,
+               "hd_hb_linear_smallk_bf16x3_f32: shape outside the fused path (d_in <= 32, d_out <= 512 and a multiple of 16)");
+    if (rows == 0) return HD_OK;
+    HD_REQUIRE(x && Wimg && out && is_aligned16(out) && is_aligned16(Wimg),
+               "hd_hb_linear_smallk_bf16x3_f32: null or misaligned pointer");
+    HD_REQUIRE(rows < (1LL << 31) * 64, "hd_hb_linear_smallk_bf16x3_f32: too many rows");
+    const size_t lds = (size_t)(d_out / 16) * 3 * 64 * 16;
+    const dim3 grid((unsigned)((rows + 63) / 64));
+#define HD_SKM(NT_)                                                                                            \
+    {                                                                                                          \
+        if (lds > 64 * 1024) {                                                                                 \
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hb_linear_smallk_mfma<NT_>), \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+            if (e != hipSuccess) {                                                                             \
+                set_error("hd_hb_linear_smallk_bf16x3_f32: hipFuncSetAttribute(%zu B of LDS): %s", lds,        \
+                          hipGetErrorString(e));                                                               \
+                return HD_EHIP;                                                                                \
+            }                                                                                                  \
+        }                                                                                                      \
+        hb_linear_smallk_mfma<NT_><<<grid, dim3(256), lds, (hipStream_t)st>>>(                                 \
+            (const float*)x, (const uint4*)Wimg, (float*)out, rows, (int)d_in, (int)d_out, mk(c), flags);      \
+    }
+    if (d_out <= 128) HD_SKM(8) else if (d_out <= 256) HD_SKM(16) else HD_SKM(32)
+#undef HD_SKM
+    return check_launch("hd_hb_linear_smallk_bf16x3_f32");
 }
 
 extern "C" int hd_hb_linear_smallk_f32(const void* x, const void* Wt, void* out, int64_t rows, int64_t d_in,

@@ -60,8 +60,13 @@ class Hyperboloid(Manifold):
             # narrow input (first layer of the graph-set configs): logmap0, the fp32 contraction and the
             # row tail in one launch -- nothing between x and the result touches memory
             out = torch.empty(x2.shape[0], N, dtype=torch.float32, device=x2.device)
-            ops._lib.call("hd_hb_linear_smallk_f32", ops._p(x2), ops._p(ops.transposed_cached(m)), ops._p(out),
-                          x2.shape[0], K, N, ops.curv(c), _flags, ops._stream())
+            if ops.GEMM_MODE != "exact" and K <= 32 and N % 16 == 0:
+                # the contraction on the matrix cores (3 bf16 limbs, fp32-faithful), one k-step per output tile
+                ops._lib.call("hd_hb_linear_smallk_bf16x3_f32", ops._p(x2), ops._p(ops.smallk_image_cached(m)),
+                              ops._p(out), x2.shape[0], K, N, ops.curv(c), _flags, ops._stream())
+            else:
+                ops._lib.call("hd_hb_linear_smallk_f32", ops._p(x2), ops._p(ops.transposed_cached(m)), ops._p(out),
+                              x2.shape[0], K, N, ops.curv(c), _flags, ops._stream())
             return out
         fmt = ops.limb_rows_fmt(x2, m)
         if fmt:

@@ -229,6 +229,23 @@ def transposed_cached(w):
     return out
 
 
+def smallk_image_cached(w):
+    """hd_smallk_pack_w_f32 image of a weight (d_out, d_in <= 32), rebuilt when the parameter changes."""
+    key = ("smallk", id(w))
+    hit = _wt_cache.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == (w._version, w.data_ptr()):
+        return hit[2]
+    wd = w.detach()
+    if wd.stride(1) != 1:
+        wd = wd.contiguous()
+    img = torch.empty(_lib.load().hd_smallk_image_bytes(wd.shape[0]) // 4, dtype=torch.int32, device=wd.device)
+    _lib.call("hd_smallk_pack_w_f32", _p(wd), wd.stride(0), wd.shape[0], wd.shape[1], _p(img), _stream())
+    if len(_wt_cache) > 64:
+        _wt_cache.clear()
+    _wt_cache[key] = (weakref.ref(w), (w._version, w.data_ptr()), img)
+    return img
+
+
 def match_padded(x2, m):
     """A weight whose input carries zero pad columns (models/encoders._lift pads the features to
     16-byte rows once): pad the weight's K to the same width (cached per parameter version)."""

@@ -123,6 +123,13 @@ int hd_hb_linear_tail_rows_f32(const void* mu, void* out, int64_t rows, int64_t 
                                void* stream);
 int hd_hb_linear_smallk_f32(const void* x, const void* Wt, void* out, int64_t rows, int64_t d_in, int64_t d_out,
                             hd_curv c, int flags, void* stream);
+/* The same layer with the contraction on the bf16 matrix cores (fp32-faithful 3-limb split, as hd_gemm_limbs_f32):
+ * d_in <= 32, d_out <= 512 and a multiple of 16.  Wimg = hd_smallk_pack_w_f32 of W (d_out, d_in) fp32 row-major
+ * (row stride ld): hd_smallk_image_bytes(d_out) bytes, 16-byte aligned, built once per weight version. */
+int64_t hd_smallk_image_bytes(int64_t d_out);
+int hd_smallk_pack_w_f32(const void* W, int64_t ld, int64_t d_out, int64_t d_in, void* img, void* stream);
+int hd_hb_linear_smallk_bf16x3_f32(const void* x, const void* Wimg, void* out, int64_t rows, int64_t d_in,
+                                   int64_t d_out, hd_curv c, int flags, void* stream);
 
 /* ---- backward of the row maps (autograd of the encoder as lp_train.py:66-82 trains it) ------
  * Each is the vector-Jacobian product of one forward entry point above: `saved` row + incoming

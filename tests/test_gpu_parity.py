@@ -272,6 +272,41 @@ def test_hb_linear_narrow_and_tail_kernels():
             assert_close(H(got), ref.numpy(), what=f"smallk vs oracle {(n, K, N)}", atol_scale=2e-6)
 
 
+def test_hb_linear_narrow_on_matrix_cores():
+    """hd_hb_linear_smallk_bf16x3_f32 (d_in <= 32: one MFMA k-step per output tile, 3 bf16 limbs) against the exact
+    fp32 fma-chain kernel hd_hb_linear_smallk_f32 and against the oracle; c = 0.7 so the curvature terms show."""
+    from hypdiff_amd import ops
+    from oracle import manifolds as om
+    rs = np.random.RandomState(22)
+    for (n, K, N, c) in [(777, 21, 512, 1.0), (64, 24, 512, 0.7), (65, 32, 256, 0.7), (1, 1, 16, 1.0), (130, 5, 48, 2.0),
+                         (1000, 17, 128, 1.0), (15777, 24, 512, 1.0)]:
+        u = rs.standard_normal((n, K)).astype(np.float32) * 0.5 * np.exp(rs.standard_normal((n, 1))).astype(np.float32)
+        u[:, 0] = 0.0
+        if n > 3:
+            u[3, 1:] = 0.0                                                         # a row at the origin
+        x = ops.map1("hd_hb_expmap0_proj", G(u), c)
+        w = G((rs.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+        img = ops.smallk_image_cached(w)
+        assert img.numel() * 4 == ops._lib.load().hd_smallk_image_bytes(N)
+        for flags in (0, 1, 3):
+            got = torch.full((n, N), float("nan"), device="cuda")
+            ops._lib.call("hd_hb_linear_smallk_bf16x3_f32", ops._p(x), ops._p(img), ops._p(got), n, K, N, ops.curv(c),
+                          flags, ops._stream())
+            want = torch.empty(n, N, device="cuda")
+            ops._lib.call("hd_hb_linear_smallk_f32", ops._p(x), ops._p(w.t().contiguous()), ops._p(want), n, K, N,
+                          ops.curv(c), flags, ops._stream())
+            assert_close(H(got), H(want), what=f"smallk mfma {(n, K, N, c, flags)}", atol_scale=2e-6)
+        if n <= 1000:
+            ref = om.hb_proj(om.hb_mobius_matvec(torch.from_numpy(H(w)), torch.from_numpy(H(x)), c), c)
+            got = torch.empty(n, N, device="cuda")
+            ops._lib.call("hd_hb_linear_smallk_bf16x3_f32", ops._p(x), ops._p(img), ops._p(got), n, K, N, ops.curv(c), 1,
+                          ops._stream())
+            assert_close(H(got), ref.numpy(), what=f"smallk mfma vs oracle {(n, K, N, c)}", atol_scale=2e-6)
+    with pytest.raises(RuntimeError, match="outside the fused path"):
+        ops._lib.call("hd_hb_linear_smallk_bf16x3_f32", None, None, None, 4, 33, 512, ops.curv(1.0), 0, ops._stream())
+    ops._lib.call("hd_hb_linear_smallk_bf16x3_f32", None, None, None, 0, 21, 512, ops.curv(1.0), 0, ops._stream())
+
+
 def test_csr_unsorted_empty_rows_and_bounds():
     from hypdiff_amd import ops
     rs = np.random.RandomState(3)
