@@ -16,6 +16,12 @@ class HdCurv(ctypes.Structure):
     _fields_ = [("c", c_double), ("sqrt_c", c_double), ("K", c_double), ("sqrt_K", c_double)]
 
 
+class HdChainLayer(ctypes.Structure):
+    """struct hd_chain_layer of include/hypdiff.h"""
+    _fields_ = [("wimg", c_void_p), ("bias", c_void_p), ("d_in", c_int32), ("d_out", c_int32), ("epi", c_int32),
+                ("add_emb", c_int32)]
+
+
 P = c_void_p
 I64 = c_int64
 _map1 = [P, P, I64, I64, HdCurv, P]
@@ -34,6 +40,8 @@ SIZE_QUERIES = {
     "hd_limb_image_bytes": [I64, I64],
     "hd_limb_image_bytes_f16x2": [I64, I64],
     "hd_smallk_image_bytes": [I64],
+    "hd_chain_image_bytes": [I64, I64],
+    "hd_chain_workspace_bytes": [],
 }
 
 # name -> argtypes; names ending in "*" exist as _f32 and _f64
@@ -64,6 +72,9 @@ SIGNATURES = {
     "hd_hb_linear_tail_rows_f32": [P, P, I64, I64, HdCurv, c_int, P],
     "hd_hb_linear_smallk_f32": [P, P, P, I64, I64, I64, HdCurv, c_int, P],
     "hd_smallk_pack_w_f32": [P, I64, I64, I64, P, P],
+    "hd_chain_pack_w_f32": [P, I64, I64, I64, P, P],
+    "hd_linear_chain_small_f32": [P, I64, I64, POINTER(HdChainLayer), c_int, P, P, I64, P, I64, P, I64, P],
+    "hd_chain_failed": [P, P],
     "hd_hb_linear_smallk_bf16x3_f32": [P, P, P, I64, I64, I64, HdCurv, c_int, P],
     "hd_csr_from_coo": [P, P, I64, I64, I64, P, P, P, P],
     "hd_adj_count": [P, P, I64, P, P, P],

@@ -488,6 +488,66 @@ def linear_chain(x, layers):
     return xf
 
 
+CHAIN_SMALL_MAX_ROWS, CHAIN_SMALL_MAX_WIDTH = 512, 512
+_NO_CHAIN_SMALL = bool(os.environ.get("HD_NO_CHAIN_SMALL"))     # debugging knob: one GEMM launch per layer
+_chain_ws = {}
+
+
+def chain_image_cached(w):
+    """hd_chain_pack_w_f32 image of a weight (d_out, d_in), rebuilt when the parameter changes."""
+    key = ("chain", id(w))
+    hit = _wt_cache.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == (w._version, w.data_ptr()):
+        return hit[2]
+    wd = w.detach()
+    if wd.stride(1) != 1:
+        wd = wd.contiguous()
+    img = torch.empty(_lib.load().hd_chain_image_bytes(wd.shape[0], wd.shape[1]) // 4, dtype=torch.int32, device=wd.device)
+    _lib.call("hd_chain_pack_w_f32", _p(wd), wd.stride(0), wd.shape[0], wd.shape[1], _p(img), _stream())
+    if len(_wt_cache) > 256:
+        _wt_cache.clear()
+    _wt_cache[key] = (weakref.ref(w), (w._version, w.data_ptr()), img)
+    return img
+
+
+def chain_small_ok(x, layers):
+    """The one-launch chain (hd_linear_chain_small_f32) applies: small fp32 batch, every layer <= 512 wide, inner
+    widths multiples of 32, fp32-faithful limb arithmetic allowed (GEMM_MODE "exact" keeps the per-layer exact GEMMs)."""
+    if _NO_CHAIN_SMALL or GEMM_MODE == "exact" or x.dtype != torch.float32 or x.dim() != 2:
+        return False
+    if not (0 < x.shape[0] <= CHAIN_SMALL_MAX_ROWS) or len(layers) > 32:
+        return False
+    for i, (w, b, epi) in enumerate(layers):
+        n, k = w.shape
+        if max(n, k) > CHAIN_SMALL_MAX_WIDTH or w.dtype != torch.float32 or (i + 1 < len(layers) and n % 32):
+            return False
+    return True
+
+
+def linear_chain_small(x, layers, emb_after=None, emb=None, emb_idx=None):
+    """layers = [(weight, bias, epi), ...] as linear_chain; after layer `emb_after` the rows of `emb` selected by
+    `emb_idx` (int64) are added (ddpm.py:39).  One cooperative launch; the workspace is kept per device and stream."""
+    _dev(x)
+    x = x if x.stride(1) == 1 else x.contiguous()
+    n = x.shape[0]
+    arr = (_lib.HdChainLayer * len(layers))()
+    keep = []
+    for i, (w, b, epi) in enumerate(layers):
+        img = chain_image_cached(w)
+        bd = None if b is None else b.detach()
+        keep += [img, bd]
+        arr[i] = _lib.HdChainLayer(_p(img), _p(bd), w.shape[1], w.shape[0], epi, 1 if emb_after == i else 0)
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _chain_ws.get(key)
+    if ws is None:
+        ws = _chain_ws[key] = torch.empty(_lib.load().hd_chain_workspace_bytes() // 4, dtype=torch.int32, device=x.device)
+    out = torch.empty(n, layers[-1][0].shape[0], dtype=torch.float32, device=x.device)
+    tab = None if emb is None else emb.detach()
+    _lib.call("hd_linear_chain_small_f32", _p(x), x.stride(0), n, arr, len(layers), _p(tab), _p(emb_idx),
+              0 if tab is None else tab.shape[0], _p(out), out.stride(0), _p(ws), ws.numel() * 4, _stream())
+    return out
+
+
 # ---- adjacency -------------------------------------------------------------------
 class CSR:
     """Device CSR (int32 rowptr/col, values in the COO's dtype and entry order)."""

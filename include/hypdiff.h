@@ -262,6 +262,28 @@ int hd_gemm_f32_bf16x3(const void* A, const void* W, const void* bias, const voi
 int64_t hd_limb_image_bytes(int64_t rows, int64_t cols);
 int hd_limb_pack_f32(const void* in, int64_t ld, int64_t rows, int64_t cols, void* out, void* stream);
 int hd_limb_unpack_f32(const void* in, int64_t rows, int64_t cols, void* out, int64_t ld, void* stream);
+/* A stack of nn.Linear layers on a small batch (rows <= 512, widths <= 512) in ONE cooperative launch: MLP.forward /
+ * Backbone.forward of ddpm.py:9-41 (config 3: 24 layers of width 512 at B = 200).  Layer i: y = x W_i^T + bias_i, then
+ * epi 0 nothing, 1 erf-GELU, 2 x + GELU(y) (ddpm.py:20-22; d_in == d_out); add_emb != 0: y += emb[emb_idx[row]]
+ * afterwards (ddpm.py:39, emb (emb_rows, d_out) fp32 contiguous; an index outside [0, emb_rows) gives a NaN row).  wimg
+ * = hd_chain_pack_w_f32 of W_i (d_out, d_in) fp32 row-major, hd_chain_image_bytes(d_out, d_in) bytes, 16-byte aligned;
+ * inner widths are multiples of 32.  Arithmetic as hd_gemm_limbs_f32 (3 bf16 limbs, fp32-faithful).  workspace:
+ * hd_chain_workspace_bytes() bytes of device memory, 16-byte aligned, private to the call while it runs.  The launch
+ * is cooperative (hipLaunchCooperativeKernel: 256 workgroups resident at once); hd_chain_failed(workspace, stream)
+ * returns 1 if a group barrier of the last launch timed out (outputs are NaN then) -- it synchronises the stream. */
+typedef struct {
+    const void* wimg;
+    const void* bias;
+    int32_t d_in, d_out, epi, add_emb;
+} hd_chain_layer;
+int64_t hd_chain_image_bytes(int64_t d_out, int64_t d_in);
+int64_t hd_chain_workspace_bytes(void);
+int hd_chain_pack_w_f32(const void* W, int64_t ld, int64_t d_out, int64_t d_in, void* img, void* stream);
+int hd_linear_chain_small_f32(const void* x, int64_t ldx, int64_t rows, const hd_chain_layer* layers, int n_layers,
+                              const void* emb, const int64_t* emb_idx, int64_t emb_rows, void* out, int64_t ldo,
+                              void* workspace, int64_t workspace_bytes, void* stream);
+int hd_chain_failed(const void* workspace, void* stream);
+
 /* One-pass producers of bf16x3 GEMM operands (no fp32 staging copy, one read of the rows): cat(x.float(),
  * t[:,None]) of models/direction_diffusion.py:57-58 (x f32/f64 by x_dtype 0/1, t as in hd_mlp_pack_input;
  * dim + 1 <= 1024), and the operands of HypLinear (dim <= 1024): mode 1 = Hyperboloid.logmap0(x, c)

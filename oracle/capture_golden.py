@@ -391,6 +391,39 @@ def capture_ddpm(out_dir):
     print("ddpm", len(store), "arrays")
 
 
+def capture_ddpm_big(out_dir):
+    """ddpm.Model / DDPMSampler at config 3's real size (diff_graphset.py:191: latents of width 64, hidden 512,
+    10 layers, T = 1000) on B = 200 latents; the weights are oracle.golden_inputs.ddpm_state(...), so only
+    inputs and outputs are stored."""
+    import ddpm as rddpm
+    import ddpm_utils as rutils
+    from oracle import golden_inputs as gi
+    store = {}
+    rs = np.random.RandomState(2708)
+    B, D, Hd, L, Tn = 200, 64, 512, 10, 1000
+    model = rddpm.Model(D, Hd, L, Tn, 1e-4, 0.02).eval()
+    model.load_state_dict(gi.ddpm_state(D, Hd, L, Tn))
+    x = T(rs.standard_normal((B, D)).astype(np.float32))
+    idx = T(rs.randint(0, Tn, size=B).astype(np.int64))
+    store["x"], store["idx"] = N(x), N(idx)
+    with torch.no_grad():
+        store["backbone"] = N(model.backbone(x, idx))
+        store["backbone_f64"] = N(model.double().backbone(x.double(), idx))      # conditioning yardstick
+        model.float()
+        store["infer_t500"] = N(model(x, 500))
+        sampler = rutils.DDPMSampler(1e-4, 0.02, Tn, model, "cpu", (D,))
+        noises = [T(rs.standard_normal((B, D)).astype(np.float32)) for _ in range(2)]
+        it = iter(noises)
+        with injected(randn_like=lambda *a, **k: next(it).clone()):
+            gen = sampler._one_diffusion_step(x.clone(), torch.sign(x), False, 'pred_noise')
+            for i in range(2):
+                store[f"sampler/step{i}"] = N(next(gen))
+        for i, nz in enumerate(noises):
+            store[f"sampler/noise{i}"] = N(nz)
+    np.savez_compressed(os.path.join(out_dir, "ddpm_big.npz"), **store)
+    print("ddpm_big", len(store), "arrays")
+
+
 def capture_train(out_dir):
     """Gradients of the two denoiser training losses, taken by the reference's own autograd:
     diffusion.forward (models/direction_diffusion.py:335-363, mlp denoiser) as diff.py:113-118
@@ -651,6 +684,8 @@ def main():
         capture_diffusionset(out)
     if a.only in ("", "ddpm"):
         capture_ddpm(out)
+    if a.only in ("", "ddpm_big"):
+        capture_ddpm_big(out)
     if a.only in ("", "train"):
         capture_train(out)
     if a.only in ("", "extras"):

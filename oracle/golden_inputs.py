@@ -91,3 +91,26 @@ def diffusion_case(n, dim, k=3, seed=1432, dtype=np.float32):
     noise = rs.standard_normal((n, dim))
     img = rs.standard_normal((n, dim)).astype(np.float32)
     return dict(x=x, u0=u0, labels=labels, noise=noise, img=img, rs=rs)
+
+
+def ddpm_state(dim_in, hidden, num_layer, n_steps, seed=1432):
+    """Seeded state_dict of ddpm.Model's backbone (ddpm.py:30-41) at any size: nn.Linear-style uniform(+-1/sqrt(fan_in))
+    weights and biases, N(0, 1) embedding rows.  The same function feeds the reference at capture time and the
+    oracle / HIP path at test time, so a fixture at the real size (hidden 512, 10 layers: 6.3 M weights) only holds
+    inputs and outputs."""
+    import torch
+    rs = np.random.RandomState(seed)
+    sd = {}
+
+    def linear(prefix, n_out, n_in):
+        b = 1.0 / np.sqrt(n_in)
+        sd[prefix + ".weight"] = torch.from_numpy(rs.uniform(-b, b, size=(n_out, n_in)).astype(np.float32))
+        sd[prefix + ".bias"] = torch.from_numpy(rs.uniform(-b, b, size=n_out).astype(np.float32))
+
+    for name, d_in, d_out in (("backbone.linear_model1", dim_in, hidden), ("backbone.linear_model2", hidden, dim_in)):
+        linear(f"{name}.layers.0", hidden, d_in)
+        for i in range(num_layer):
+            linear(f"{name}.layers.{i + 1}", hidden, hidden)
+        linear(f"{name}.layers.{num_layer + 1}", d_out, hidden)
+    sd["backbone.embedding_layer.weight"] = torch.from_numpy(rs.standard_normal((n_steps, hidden)).astype(np.float32))
+    return sd

@@ -64,3 +64,103 @@ def test_hip_ddpm_golden(golden, gemm_mode, monkeypatch):
             assert_close(xs.cpu(), g[f"sampler/step{i}"], what=f"sampler {i}")
         fin = s.sampling(7, x, only_final=True)
         assert fin.shape == (7, D) and bool(torch.isfinite(fin).all())
+
+
+# ---- config 3 at its real size: hidden 512, 10 layers, B = 200 (diff_graphset.py:191) -----------------------------
+BIG = dict(B=200, D=64, Hd=512, L=10, Tn=1000)
+
+
+def _big_parts():
+    from oracle import golden_inputs as gi
+    sd = gi.ddpm_state(BIG["D"], BIG["Hd"], BIG["L"], BIG["Tn"])
+    m = lambda pre: [(sd[f"{pre}.layers.{i}.weight"], sd[f"{pre}.layers.{i}.bias"]) for i in range(BIG["L"] + 2)]
+    return sd, m("backbone.linear_model1"), sd["backbone.embedding_layer.weight"], m("backbone.linear_model2")
+
+
+def test_oracle_ddpm_big_golden(golden):
+    """the oracle's backbone / sampler step against the reference's outputs at hidden 512 x 10 layers"""
+    g = golden("ddpm_big")
+    sd, m1, emb, m2 = _big_parts()
+    x, idx = torch.from_numpy(g["x"]), torch.from_numpy(g["idx"])
+    beta, ab = oddpm.schedule(BIG["Tn"], 1e-4, 0.02)
+    ex = g["backbone_f64"]
+    assert_close(oddpm.backbone(x, idx, m1, emb, m2), g["backbone"], exact=ex, what="backbone 512x10")
+    assert_close(oddpm.backbone(x, torch.full((BIG["B"],), 500), m1, emb, m2), g["infer_t500"], what="infer 512x10")
+    xs = x.clone()
+    for i in range(2):
+        t = BIG["Tn"] - 1 - i
+        e = oddpm.backbone(xs, torch.full((BIG["B"],), t), m1, emb, m2)
+        xs = oddpm.sampler_step(xs, t, e, torch.from_numpy(g[f"sampler/noise{i}"]), beta, ab)
+        assert_close(xs, g[f"sampler/step{i}"], what=f"sampler step {i} 512x10")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gemm_mode", ["bf16x3", "f16x2", "exact"])
+def test_hip_ddpm_big_golden(golden, gemm_mode, monkeypatch):
+    """Backbone at the real size: one cooperative launch for the 24 layers (bf16x3 / f16x2 modes; `exact` keeps a
+    launch per layer), against the reference's outputs and against the launch-per-layer path."""
+    from hypdiff_amd import ops
+    from hypdiff_amd.ddpm import Model
+    from hypdiff_amd.ddpm_utils import DDPMSampler
+    monkeypatch.setattr(ops, "GEMM_MODE", gemm_mode)
+    g = golden("ddpm_big")
+    sd, _, _, _ = _big_parts()
+    model = Model(BIG["D"], BIG["Hd"], BIG["L"], BIG["Tn"], 1e-4, 0.02).cuda().eval()
+    model.load_state_dict(sd)
+    x, idx = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["idx"]).cuda()
+    ex = g["backbone_f64"]
+    with torch.no_grad():
+        got = model.backbone(x, idx)
+        assert_close(got.cpu(), g["backbone"], exact=ex, what="backbone 512x10")
+        assert_close(model(x, 500).cpu(), g["infer_t500"], what="infer 512x10")
+        if gemm_mode != "exact":
+            ws = ops._chain_ws[(x.device.index, torch.cuda.current_stream().cuda_stream)]
+            assert ops._lib.load().hd_chain_failed(ops._p(ws), ops._stream()) == 0
+            monkeypatch.setattr(ops, "_NO_CHAIN_SMALL", True)
+            per_layer = model.backbone(x, idx)
+            monkeypatch.setattr(ops, "_NO_CHAIN_SMALL", False)
+            assert_close(got.cpu(), per_layer.cpu(), exact=ex, what="one launch vs launch per layer")
+            # ragged batches: 1 row, a partial tile, one group only, the largest batch of the one-launch path
+            for b in (1, 17, 129, 512):
+                xb = torch.randn(b, BIG["D"], device="cuda", generator=torch.Generator("cuda").manual_seed(b))
+                ib = torch.randint(0, BIG["Tn"], (b,), device="cuda", generator=torch.Generator("cuda").manual_seed(b))
+                one = model.backbone(xb, ib)
+                monkeypatch.setattr(ops, "_NO_CHAIN_SMALL", True)
+                ref = model.backbone(xb, ib)
+                monkeypatch.setattr(ops, "_NO_CHAIN_SMALL", False)
+                assert_close(one.cpu(), ref.cpu(), what=f"one launch vs launch per layer, B={b}", atol_scale=3e-6)
+            bad = idx.clone()
+            bad[5] = BIG["Tn"]                          # nn.Embedding would raise: the row comes back NaN
+            out = model.backbone(x, bad)
+            assert bool(torch.isnan(out[5]).all()) and bool(torch.isfinite(out[:5]).all()) and bool(torch.isfinite(out[6:]).all())
+        s = DDPMSampler(1e-4, 0.02, BIG["Tn"], model, "cuda", (BIG["D"],))
+        xs = x.clone()
+        for i in range(2):
+            xs = s.one_step(xs, BIG["Tn"] - 1 - i, torch.from_numpy(g[f"sampler/noise{i}"]).cuda())
+            assert_close(xs.cpu(), g[f"sampler/step{i}"], what=f"sampler {i} 512x10")
+
+
+@pytest.mark.gpu
+def test_linear_chain_small_shapes():
+    """hd_linear_chain_small_f32 on stacks that are not the Backbone: narrow first / last layers, a residual first
+    layer, no bias, widths that leave k-steps and column tiles partly empty -- against fp64 on the host."""
+    from hypdiff_amd import ops
+    rs = np.random.RandomState(5)
+    for rows, dims, epis in [(200, [64, 512, 512, 64], [1, 2, 0]), (33, [7, 32, 32, 5], [1, 2, 0]),
+                             (512, [96, 96, 160, 3], [2, 1, 0]), (16, [512, 512], [2]), (5, [20, 13], [0])]:
+        ws = [torch.from_numpy((rs.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32)).cuda()
+              for i in range(len(epis))]
+        bs = [None if i == 1 else torch.from_numpy(rs.standard_normal(dims[i + 1]).astype(np.float32)).cuda()
+              for i in range(len(epis))]
+        x = torch.from_numpy(rs.standard_normal((rows, dims[0])).astype(np.float32)).cuda()
+        layers = list(zip(ws, bs, epis))
+        assert ops.chain_small_ok(x, layers)
+        got = ops.linear_chain_small(x, layers)
+        h = x.double().cpu()
+        for w, b, e in layers:
+            z = h @ w.double().cpu().T + (0 if b is None else b.double().cpu())
+            h = z if e == 0 else (torch.nn.functional.gelu(z) if e == 1 else h + torch.nn.functional.gelu(z))
+        assert_close(got.cpu().numpy(), h.numpy(), what=f"chain {rows} x {dims}", atol_scale=3e-6)
+    assert not ops.chain_small_ok(torch.zeros(513, 64, device="cuda"), layers)
+    with pytest.raises(RuntimeError, match="rows must be"):
+        ops._lib.call("hd_linear_chain_small_f32", None, 64, 513, None, 1, None, None, 0, None, 64, None, 0, ops._stream())
