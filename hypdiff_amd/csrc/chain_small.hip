@@ -4,8 +4,8 @@
 // step in round 1).  Replaces MLP.forward / Backbone.forward of ddpm.py:9-41 for rows <= 512.
 //
 // Layout of the work: the rows are cut into 8 groups (one per XCD: workgroup b belongs to group b & 7, and the
-// dispatcher deals workgroups round-robin over the XCDs, so a group's activations stay in one L2 -- a
-// performance assumption only, correctness rests on agent-scope release / acquire).  A group of G workgroups
+// dispatcher deals workgroups round-robin over the XCDs, so a group's activations stay near one L2 -- a
+// performance assumption only, correctness rests on agent-scope atomics).  A group of G workgroups
 // walks the layers together; workgroup g owns output columns 16 g .. 16 g + 15 of every layer: its four
 // wavefronts split K (k-steps w, w + 4, ...), each multiplying up to 4 row tiles of 16 rows with
 // v_mfma_f32_16x16x32_bf16 on 3 bf16 limbs (6 MFMAs per fp32 product block: fp32-faithful, as the limb GEMM),
@@ -14,8 +14,7 @@
 // layer.  Weights come pre-split in exactly the per-lane operand order (hd_chain_pack_w_f32), straight from L2
 // into registers -- with 16..64 rows per group a weight fragment is used by one wavefront only, LDS staging
 // would add nothing -- and the loads of layer l + 1 are issued before the group waits for layer l's
-// activations.  Between layers the group meets at a counter: release (fence + atomic add) after the stores,
-// acquire (spin on the counter, fence) before the loads.  The launch is cooperative (every workgroup resident:
+// activations.  Between layers the group meets at a counter (group_arrive / group_wait below).  The launch is cooperative (every workgroup resident:
 // the spin cannot starve a workgroup that has not started), and the spin is bounded by a 2 s wall clock after
 // which the group raises the workspace's fail flag and writes NaN instead of hanging.
 #include "hd_common.cuh"
@@ -55,10 +54,39 @@ constexpr size_t kActlBytes = (size_t)kGroups * kMaxRT * kMaxKS * 3 * 64 * sizeo
 constexpr size_t kActfBytes = (size_t)kMaxRows * kMaxW * sizeof(float);
 constexpr size_t kWsBytes = 256 + 2 * kActlBytes + 2 * kActfBytes;
 
+// Activations cross workgroups (and possibly XCDs, whose L2s are not coherent with each other for ordinary
+// accesses).  An agent-scope release / acquire FENCE would do it, but on this chip it is a whole-L2 write-back /
+// invalidate per workgroup and layer (measured: 38 us per layer, and the spinning acquires kept throwing the
+// weights out of L2).  Instead every activation access is a relaxed agent-scope ATOMIC load / store of 8 bytes
+// (global_load / global_store with sc1: coherent at the agent level per location, no cache-wide operation), the
+// producer drains its stores (vmcnt(0)) before its workgroup bumps the group counter, and the consumer issues its
+// loads only after it has seen the counter: no fences.
+__device__ __forceinline__ void st_u2(void* p, uint2 v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint2 ld_u2(const void* p) {
+    const unsigned long long q = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint2((unsigned)q, (unsigned)(q >> 32));
+}
+__device__ __forceinline__ void st_u4(uint4* p, uint4 v) {
+    st_u2(p, make_uint2(v.x, v.y));
+    st_u2(reinterpret_cast<uint2*>(p) + 1, make_uint2(v.z, v.w));
+}
+__device__ __forceinline__ uint4 ld_u4(const uint4* p) {
+    const uint2 a = ld_u2(p), b = ld_u2(reinterpret_cast<const uint2*>(p) + 1);
+    return make_uint4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ void st_f(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_f(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __device__ __forceinline__ void group_arrive(int* ctr) {
-    __threadfence();                           // this thread's stores are visible at agent scope
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's activation stores have been acknowledged
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // true = the group is complete; false = timed out or another workgroup raised the fail flag
 __device__ __forceinline__ bool group_wait(int* ctr, int target, int* fail) {
@@ -66,7 +94,7 @@ __device__ __forceinline__ bool group_wait(int* ctr, int target, int* fail) {
     if (threadIdx.x == 0) {
         int ok = 1;
         const uint64_t t0 = wall_clock64();
-        while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
             if (wall_clock64() - t0 > 200000000ull ||
                 __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
@@ -78,7 +106,7 @@ __device__ __forceinline__ bool group_wait(int* ctr, int target, int* fail) {
         ok_s = ok;
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("" ::: "memory");
     return ok_s != 0;
 }
 
@@ -110,12 +138,12 @@ __global__ __launch_bounds__(256) void linear_chain_small(const float* __restric
             for (int e = 0; e < 8; ++e) {
                 const int k = ks * 32 + 8 * kq + e;
                 v[e] = (row < rows && k < K0) ? x[(size_t)row * ldx + k] : 0.f;
-                if (k < K0) actf[0][(size_t)rl * kMaxW + k] = v[e];
+                if (k < K0) st_f(&actf[0][(size_t)rl * kMaxW + k], v[e]);
             }
             uint4 h, m, l;
             limb_split8(v, h, m, l);
             uint4* o = actl[0] + ((size_t)(it * kMaxKS + ks) * 3) * 64 + lane;
-            o[0] = h; o[64] = m; o[128] = l;
+            st_u4(o, h); st_u4(o + 64, m); st_u4(o + 128, l);
         }
     }
     group_arrive(ctr);
@@ -144,24 +172,41 @@ __global__ __launch_bounds__(256) void linear_chain_small(const float* __restric
             if (!work) break;
             // operand maps of v_mfma_f32_16x16x32: first = W rows (n = 16 jt + r16), second = activation rows
             // (m = r16), k = 8 kq .. 8 kq + 7 of the k-step; D column = lane & 15 = m, D rows 4 kq + reg = n
+            // two row tiles at a time: all their fragment loads are issued before the first multiply, so the
+            // tiles share one memory round trip (the loads are agent-scope atomics: the compiler keeps their order)
 #pragma unroll
-            for (int it = 0; it < kMaxRT; ++it) {
-                if (it < RT) {
-                    lf32x4 c = {0.f, 0.f, 0.f, 0.f};
+            for (int it0 = 0; it0 < kMaxRT; it0 += 2) {
+                if (it0 < RT) {
+                    uint4 af[2][kMaxKS / 4][3];
 #pragma unroll
-                    for (int q = 0; q < kMaxKS / 4; ++q) {
-                        const int ks = wave + 4 * q;
-                        if (ks < KS) {
-                            const uint4* a = actl[cur] + ((size_t)(it * kMaxKS + ks) * 3) * 64 + lane;
-                            const uint4 a0 = a[0], a1 = a[64], a2 = a[128];
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int q = 0; q < kMaxKS / 4; ++q) {
+                            const int ks = wave + 4 * q;
+                            if (it0 + h < RT && ks < KS) {
+                                const uint4* a = actl[cur] + ((size_t)((it0 + h) * kMaxKS + ks) * 3) * 64 + lane;
+                                af[h][q][0] = ld_u4(a); af[h][q][1] = ld_u4(a + 64); af[h][q][2] = ld_u4(a + 128);
+                            } else {
+                                af[h][q][0] = af[h][q][1] = af[h][q][2] = make_uint4(0, 0, 0, 0);
+                            }
+                        }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        if (it0 + h < RT) {
+                            lf32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int q = 0; q < kMaxKS / 4; ++q) {
+                                if (wave + 4 * q < KS) {
 #define HD_MM(wv, av) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lbf16x8, wv), \
                                                           __builtin_bit_cast(lbf16x8, av), c, 0, 0, 0);
-                            HD_MM(wf[q][0], a2) HD_MM(wf[q][2], a0) HD_MM(wf[q][1], a1)
-                            HD_MM(wf[q][0], a1) HD_MM(wf[q][1], a0) HD_MM(wf[q][0], a0)
+                                    HD_MM(wf[q][0], af[h][q][2]) HD_MM(wf[q][2], af[h][q][0]) HD_MM(wf[q][1], af[h][q][1])
+                                    HD_MM(wf[q][0], af[h][q][1]) HD_MM(wf[q][1], af[h][q][0]) HD_MM(wf[q][0], af[h][q][0])
 #undef HD_MM
+                                }
+                            }
+                            red[wave][it0 + h][lane] = make_float4(c[0], c[1], c[2], c[3]);
                         }
                     }
-                    red[wave][it][lane] = make_float4(c[0], c[1], c[2], c[3]);
                 }
             }
             __syncthreads();
@@ -182,7 +227,7 @@ __global__ __launch_bounds__(256) void linear_chain_small(const float* __restric
                     if (n < L.N) {
                         y = v[e] + (L.bias ? L.bias[n] : 0.f);
                         if (L.epi == 1) y = gelu_erfc(y);
-                        else if (L.epi == 2) y = actf[cur][(size_t)rl * kMaxW + n] + gelu_erfc(y);
+                        else if (L.epi == 2) y = ld_f(&actf[cur][(size_t)rl * kMaxW + n]) + gelu_erfc(y);
                         if (er >= 0 && er < emb_rows) y += emb[er * (int64_t)L.N + n];
                         else if (L.add_emb && row < rows) y = __builtin_nanf("");    // index out of range (nn.Embedding raises)
                     }
@@ -195,7 +240,9 @@ __global__ __launch_bounds__(256) void linear_chain_small(const float* __restric
                             if (nb + e < L.N) out[(size_t)row * ldo + nb + e] = ok ? v[e] : __builtin_nanf("");
                     }
                 } else {
-                    *reinterpret_cast<float4*>(actf[nxt] + (size_t)rl * kMaxW + nb) = make_float4(v[0], v[1], v[2], v[3]);
+                    float* fo = actf[nxt] + (size_t)rl * kMaxW + nb;
+                    st_u2(fo, make_uint2(__float_as_uint(v[0]), __float_as_uint(v[1])));
+                    st_u2(fo + 2, make_uint2(__float_as_uint(v[2]), __float_as_uint(v[3])));
                     // columns 16 jt .. + 15 = half a k-step of the next layer: lane (r16, 2 (jt & 1) + (kq >> 1)),
                     // 8-byte half kq & 1
                     unsigned hh[2], mm[2], ll[2];
@@ -208,9 +255,9 @@ __global__ __launch_bounds__(256) void linear_chain_small(const float* __restric
                     }
                     const int ln = r16 + 16 * (2 * (jt & 1) + (kq >> 1));
                     uint2* o = reinterpret_cast<uint2*>(actl[nxt] + ((size_t)(it * kMaxKS + (jt >> 1)) * 3) * 64 + ln) + (kq & 1);
-                    o[0] = make_uint2(hh[0], hh[1]);
-                    o[2 * 64] = make_uint2(mm[0], mm[1]);
-                    o[2 * 128] = make_uint2(ll[0], ll[1]);
+                    st_u2(o, make_uint2(hh[0], hh[1]));
+                    st_u2(o + 2 * 64, make_uint2(mm[0], mm[1]));
+                    st_u2(o + 2 * 128, make_uint2(ll[0], ll[1]));
                 }
             }
             __syncthreads();                                       // red[] is free again
