@@ -3,20 +3,32 @@
 // chip-filling tile grid each, so a launch per layer spends its time on launch ramps (0.58 ms per sampler
 // step in round 1).  Replaces MLP.forward / Backbone.forward of ddpm.py:9-41 for rows <= 512.
 //
-// Layout of the work: the rows are cut into 8 groups (one per XCD: workgroup b belongs to group b & 7, and the
-// dispatcher deals workgroups round-robin over the XCDs, so a group's activations stay near one L2 -- a
-// performance assumption only, correctness rests on agent-scope atomics).  A group of G workgroups
-// walks the layers together; workgroup g owns output columns 16 g .. 16 g + 15 of every layer: its four
-// wavefronts split K (k-steps w, w + 4, ...), each multiplying up to 4 row tiles of 16 rows with
-// v_mfma_f32_16x16x32_bf16 on 3 bf16 limbs (6 MFMAs per fp32 product block: fp32-faithful, as the limb GEMM),
-// the partial tiles meet in LDS, wavefront `it` finishes row tile `it`: bias, erf-GELU, residual, time
-// embedding; the result goes out as fp32 (the next residual) and as limbs in the A-operand order of the next
-// layer.  Weights come pre-split in exactly the per-lane operand order (hd_chain_pack_w_f32), straight from L2
-// into registers -- with 16..64 rows per group a weight fragment is used by one wavefront only, LDS staging
-// would add nothing -- and the loads of layer l + 1 are issued before the group waits for layer l's
-// activations.  Between layers the group meets at a counter (group_arrive / group_wait below).  The launch is cooperative (every workgroup resident:
-// the spin cannot starve a workgroup that has not started), and the spin is bounded by a 2 s wall clock after
-// which the group raises the workspace's fail flag and writes NaN instead of hanging.
+// Layout of the work: the row tiles (16 rows) are dealt to up to 16 groups of 16 workgroups (workgroup b is
+// member b >> 4 of group b & 15; one or two row tiles per group).  A group walks the layers together; member g
+// owns output columns 32 g .. 32 g + 31 of every layer (two 16-column MFMA tiles): its four wavefronts split K
+// (k-steps w, w + 4, ...), each multiplying with v_mfma_f32_16x16x32_bf16 on 3 bf16 limbs (6 MFMAs per fp32
+// product block: fp32-faithful, as the limb GEMM), the partial tiles meet in LDS, one wavefront per output tile
+// finishes it: bias, erf-GELU, residual (the tile's previous value is still in that wavefront's registers), time
+// embedding.  Weights come pre-split in exactly the per-lane operand order (hd_chain_pack_w_f32), straight from
+// L2 into registers -- a weight fragment is used by one wavefront only, LDS staging would add nothing.  The 24
+// matrices are 37 MB, so every layer's slice misses L2: it is requested as soon as the previous layer's multiplies
+// have released the registers, one hand-over ahead of its use (the bias / embedding values a tile's write-out
+// needs are loaded before that request: a wavefront's loads return in order).
+//
+// Between layers nothing synchronises but the data itself.  An activation element travels as ONE 8-byte word:
+// its three bf16 limbs and a 16-bit tag (launch epoch, layer).  Words are written and read with relaxed
+// agent-scope atomics (global_store / global_load ... sc1: coherent per location across CUs and XCDs, no
+// cache-wide operation), an 8-byte atomic arrives whole, so a consumer that sees the tag it is waiting for has
+// the element; it simply re-reads the words whose tag is still old.  One fabric round trip per layer instead of
+// four (store drain, counter add, counter poll, data load: the counter version ran 8.6 us per layer at B = 200;
+// agent-scope release / acquire FENCES, the textbook form, 38 us -- on this chip they write back / invalidate the
+// whole L2 per workgroup and layer).  The two word buffers alternate by layer; a workgroup writes layer l's output
+// only after it has read all of layer l's input, which exists only once every member has finished reading layer
+// l - 1's input -- the buffer being overwritten.  Tags never repeat inside the workspace: the epoch (1..2046) lives
+// in the workspace header, the last workgroup to leave a launch advances it and, when it wraps, zeroes the words
+// (tag 0 is never waited for; the caller zero-fills a new workspace once).  The launch is cooperative (every
+// workgroup resident: a spinning consumer cannot starve a producer that has not started), and every wait is
+// bounded by a 2 s wall clock, after which the workgroup raises the fail flag and the outputs are NaN.
 #include "hd_common.cuh"
 #include "hd_gelu.cuh"
 #include "hd_limbs.cuh"
@@ -26,11 +38,12 @@ using namespace hd;
 
 namespace {
 
-constexpr int kGroups = 8, kG = 32;            // groups (XCDs) x workgroups per group = 256 workgroups
+constexpr int kGroups = 16, kG = 16;           // groups x members = 256 workgroups
 constexpr int kMaxW = 512;                     // widest layer (input or output)
-constexpr int kMaxKS = kMaxW / 32, kMaxRT = 4; // k-steps per layer, row tiles of 16 per group
+constexpr int kMaxKS = kMaxW / 32, kMaxRT = 2; // k-steps per layer, row tiles of 16 per group
 constexpr int kMaxRows = kGroups * kMaxRT * 16;
-constexpr int kMaxLayers = 32;
+constexpr int kMaxLayers = 31;                 // 5-bit layer field of the tag, stage 0 included
+constexpr int kEpochs = 2046;                  // epochs 1..2046: tags 0x0000 and 0xffff never occur
 
 struct Layer {
     const uint4* w;       // hd_chain_pack_w_f32 image
@@ -42,227 +55,254 @@ struct Chain {
     int n;
 };
 
-// workspace: [0, 256) counters (one int per group, 32 bytes apart would be nicer for the atomics' lines but a
-// group only touches its own word) + fail flag; then the limb images and fp32 copies of the activations, two of each
-struct Ws {
-    int* ctr;
-    int* fail;
-    uint4* actl[2];       // [group][it][ks][limb][lane]
-    float* actf[2];       // [group][row in group][kMaxW]
-};
-constexpr size_t kActlBytes = (size_t)kGroups * kMaxRT * kMaxKS * 3 * 64 * sizeof(uint4);
-constexpr size_t kActfBytes = (size_t)kMaxRows * kMaxW * sizeof(float);
-constexpr size_t kWsBytes = 256 + 2 * kActlBytes + 2 * kActfBytes;
+// workspace: header (int 0: launches completed mod kEpochs, int 1: workgroups that have left the running launch,
+// int 32: fail flag), then the two word buffers [group][row tile][k-step][element 0..7 of the lane][lane]: a
+// wavefront's load / store instruction covers 512 contiguous bytes
+typedef unsigned long long u64;
+constexpr size_t kGroupWords = (size_t)kMaxRT * kMaxKS * 8 * 64;
+constexpr size_t kBufWords = (size_t)kGroups * kGroupWords;
+constexpr size_t kWsBytes = 256 + 2 * kBufWords * sizeof(u64);
 
-// Activations cross workgroups (and possibly XCDs, whose L2s are not coherent with each other for ordinary
-// accesses).  An agent-scope release / acquire FENCE would do it, but on this chip it is a whole-L2 write-back /
-// invalidate per workgroup and layer (measured: 38 us per layer, and the spinning acquires kept throwing the
-// weights out of L2).  Instead every activation access is a relaxed agent-scope ATOMIC load / store of 8 bytes
-// (global_load / global_store with sc1: coherent at the agent level per location, no cache-wide operation), the
-// producer drains its stores (vmcnt(0)) before its workgroup bumps the group counter, and the consumer issues its
-// loads only after it has seen the counter: no fences.
-__device__ __forceinline__ void st_u2(void* p, uint2 v) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint2 ld_u2(const void* p) {
-    const unsigned long long q = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-    return make_uint2((unsigned)q, (unsigned)(q >> 32));
-}
-__device__ __forceinline__ void st_u4(uint4* p, uint4 v) {
-    st_u2(p, make_uint2(v.x, v.y));
-    st_u2(reinterpret_cast<uint2*>(p) + 1, make_uint2(v.z, v.w));
-}
-__device__ __forceinline__ uint4 ld_u4(const uint4* p) {
-    const uint2 a = ld_u2(p), b = ld_u2(reinterpret_cast<const uint2*>(p) + 1);
-    return make_uint4(a.x, a.y, b.x, b.y);
-}
-__device__ __forceinline__ void st_f(float* p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float ld_f(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_w(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u64 ld_w(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__device__ __forceinline__ void group_arrive(int* ctr) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's activation stores have been acknowledged
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// true = the group is complete; false = timed out or another workgroup raised the fail flag
-__device__ __forceinline__ bool group_wait(int* ctr, int target, int* fail) {
-    __shared__ int ok_s;
-    if (threadIdx.x == 0) {
-        int ok = 1;
-        const uint64_t t0 = wall_clock64();
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > 200000000ull ||
-                __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = 0;
-                break;
-            }
-        }
-        ok_s = ok;
-    }
-    __syncthreads();
-    asm volatile("" ::: "memory");
-    return ok_s != 0;
+// one activation element -> word: limbs h | m << 16 | l << 32, tag << 48 (x = h + m + l exactly)
+__device__ __forceinline__ u64 make_word(float x, unsigned tag) {
+    const unsigned h = limb_pk_bf16(x, 0.f) & 0xffffu;
+    const float r1 = x - limb_lo(h);
+    const unsigned m = limb_pk_bf16(r1, 0.f) & 0xffffu;
+    const unsigned l = limb_pk_bf16(r1 - limb_lo(m), 0.f) & 0xffffu;
+    return (u64)(h | (m << 16)) | ((u64)(l | (tag << 16)) << 32);
 }
 
 __global__ __launch_bounds__(256) void linear_chain_small(const float* __restrict__ x, int64_t ldx, int rows,
                                                           Chain ch, const float* __restrict__ emb,
                                                           const int64_t* __restrict__ emb_idx, int emb_rows,
-                                                          float* __restrict__ out, int64_t ldo, Ws ws, int rg) {
-    __shared__ float4 red[4][kMaxRT][64];
-    const int grp = blockIdx.x & (kGroups - 1), g = blockIdx.x >> 3;
+                                                          float* __restrict__ out, int64_t ldo, int* hdr, u64* buf0,
+                                                          u64* buf1, int RT) {
+    __shared__ float4 red[4][2 * kMaxRT][64];
+    __shared__ int bad_s, last_s;
+    const int grp = blockIdx.x & (kGroups - 1), g = blockIdx.x >> 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
-    const int r0 = grp * rg;                                   // first row of the group
-    const int nr = rows - r0 < rg ? rows - r0 : rg;
-    if (nr <= 0) return;                                       // (the whole group leaves: it has its own counter)
-    const int RT = (nr + 15) >> 4;
-    int* ctr = ws.ctr + grp;
-    uint4* actl[2] = {ws.actl[0] + (size_t)grp * kMaxRT * kMaxKS * 3 * 64, ws.actl[1] + (size_t)grp * kMaxRT * kMaxKS * 3 * 64};
-    float* actf[2] = {ws.actf[0] + (size_t)r0 * kMaxW, ws.actf[1] + (size_t)r0 * kMaxW};
+    const int epoch = hdr[0] + 1;
+    int* fail = hdr + 32;
+    const int r0 = grp * RT * 16;                              // first row of the group
+    const int nrt = r0 < rows ? ((rows - r0 + 15) >> 4 < RT ? (rows - r0 + 15) >> 4 : RT) : 0;   // its row tiles
+    // (two named pointers, not an array: indexing an array of pointers loses the global address space and the
+    // accesses become flat_load / flat_store)
+    u64* const gb0 = buf0 + (size_t)grp * kGroupWords;
+    u64* const gb1 = buf1 + (size_t)grp * kGroupWords;
     bool ok = true;
+    if (tid == 0) bad_s = 0;
+    float py[4] = {0.f, 0.f, 0.f, 0.f};                        // this thread's 4 outputs of the previous layer
+    // the output tile this wavefront finishes: column tile 2 g + jl_e, row tile it_e
+    const int jl_e = wave / kMaxRT, it_e = wave % kMaxRT;
+    const int row_e = r0 + it_e * 16 + r16;
 
-    // stage 0: x -> limb image (and fp32 copy) of the first layer's operand; (it, ks) pairs over the group's wavefronts
-    {
-        const int K0 = ch.l[0].K, KS0 = (K0 + 31) >> 5;
-        for (int p = g * 4 + wave; p < RT * KS0; p += kG * 4) {
-            const int it = p / KS0, ks = p - it * KS0;
-            const int rl = it * 16 + r16, row = r0 + rl;
-            float v[8];
+    if (nrt > 0) {
+        // stage 0: x -> words tagged (epoch, 0); (row tile, k-step) pairs over the group's wavefronts
+        {
+            const int K0 = ch.l[0].K, KS0 = (K0 + 31) >> 5;
+            const unsigned tag = (unsigned)(epoch << 5);
+            for (int p = g * 4 + wave; p < nrt * KS0; p += kG * 4) {
+                const int it = p / KS0, ks = p - it * KS0;
+                const int row = r0 + it * 16 + r16;
+                u64* o = gb0 + (size_t)(it * kMaxKS + ks) * 8 * 64 + lane;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = ks * 32 + 8 * kq + e;
-                v[e] = (row < rows && k < K0) ? x[(size_t)row * ldx + k] : 0.f;
-                if (k < K0) st_f(&actf[0][(size_t)rl * kMaxW + k], v[e]);
+                for (int e = 0; e < 8; ++e) {
+                    const int k = ks * 32 + 8 * kq + e;
+                    st_w(o + e * 64, make_word((row < rows && k < K0) ? x[(size_t)row * ldx + k] : 0.f, tag));
+                }
             }
-            uint4 h, m, l;
-            limb_split8(v, h, m, l);
-            uint4* o = actl[0] + ((size_t)(it * kMaxKS + ks) * 3) * 64 + lane;
-            st_u4(o, h); st_u4(o + 64, m); st_u4(o + 128, l);
         }
-    }
-    group_arrive(ctr);
-
-    for (int li = 0; li < ch.n; ++li) {
-        const Layer L = ch.l[li];
-        const int cur = li & 1, nxt = cur ^ 1;
-        const int KS = (L.K + 31) >> 5, NT = (L.N + 15) >> 4;
-        const bool last = li == ch.n - 1;
-        bool first_jt = true;
-        for (int jt = g; jt < NT || first_jt; jt += kG) {
-            const bool work = jt < NT;
-            // this wavefront's weight fragments (k-steps wave, wave + 4, ...): issued before the wait below
-            uint4 wf[kMaxKS / 4][3];
+        // this wavefront's weight fragments of a layer (k-steps wave, wave + 4, ...; column tiles 2 g, 2 g + 1)
+        uint4 wf[2][kMaxKS / 4][3];
+        auto load_w = [&](const Layer& L) {
+            const int KS = (L.K + 31) >> 5, NT = (L.N + 15) >> 4;
 #pragma unroll
-            for (int q = 0; q < kMaxKS / 4; ++q) {
-                const int ks = wave + 4 * q;
+            for (int jl = 0; jl < 2; ++jl)
 #pragma unroll
-                for (int l = 0; l < 3; ++l)
-                    wf[q][l] = (work && ks < KS) ? L.w[((size_t)(jt * KS + ks) * 3 + l) * 64 + lane] : make_uint4(0, 0, 0, 0);
+                for (int q = 0; q < kMaxKS / 4; ++q) {
+                    const int ks = wave + 4 * q;
+#pragma unroll
+                    for (int l = 0; l < 3; ++l)
+                        wf[jl][q][l] = (2 * g + jl < NT && ks < KS) ? L.w[((size_t)((2 * g + jl) * KS + ks) * 3 + l) * 64 + lane]
+                                                                    : make_uint4(0, 0, 0, 0);
+                }
+        };
+        load_w(ch.l[0]);
+        for (int li = 0; li < ch.n; ++li) {
+            const Layer L = ch.l[li];
+            const u64* in = (li & 1) ? gb1 : gb0;
+            u64* nxt = (li & 1) ? gb0 : gb1;
+            const int KS = (L.K + 31) >> 5, NT = (L.N + 15) >> 4;
+            const bool last = li == ch.n - 1;
+            const int njl = 2 * g + 1 < NT ? 2 : (2 * g < NT ? 1 : 0);     // this member's column tiles: 2 g, 2 g + 1
+            if (njl == 0) {                                                // (narrow layer: nothing to do here)
+                if (!last) load_w(ch.l[li + 1]);
+                continue;
             }
-            if (first_jt) {
-                ok = group_wait(ctr, kG * (li + 1), ws.fail) && ok;     // layer li's operand is complete
-                first_jt = false;
+            // what this wavefront's write-out will need from memory, requested first (loads return in order)
+            const bool fin = jl_e < njl && it_e < nrt;
+            const int nb_e = (2 * g + jl_e) * 16 + 4 * kq;
+            float bq[4] = {0.f, 0.f, 0.f, 0.f}, eq[4] = {0.f, 0.f, 0.f, 0.f};
+            bool emb_bad = false;
+            if (fin) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (L.bias && nb_e + e < L.N) bq[e] = L.bias[nb_e + e];
+                if (L.add_emb && row_e < rows) {
+                    const int64_t er = emb_idx[row_e];
+                    emb_bad = er < 0 || er >= emb_rows;             // nn.Embedding raises: the row comes back NaN
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (!emb_bad && nb_e + e < L.N) eq[e] = emb[er * (int64_t)L.N + nb_e + e];
+                }
             }
-            if (!work) break;
+            // this wavefront's share of the input: lane (r16, kq) holds row r16, k = 32 ks + 8 kq .. + 7
+            u64 aw[kMaxRT][kMaxKS / 4][8];
+            const u64 want = (u64)((epoch << 5) | li);
+            const uint64_t t0 = wall_clock64();
+            // wait on ONE word per lane first: polling the whole share while the producers are busy floods the fabric
+            if (wave < KS) {
+                const u64* rep = in + (size_t)wave * 8 * 64 + lane;
+                while (__any((ld_w(rep) >> 48) != want)) {
+                    if (wall_clock64() - t0 > 200000000ull || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < kMaxRT; ++it)
+#pragma unroll
+                for (int q = 0; q < kMaxKS / 4; ++q) {
+                    const int ks = wave + 4 * q;
+                    const bool use = it < nrt && ks < KS;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        aw[it][q][e] = use ? ld_w(in + ((size_t)(it * kMaxKS + ks) * 8 + e) * 64 + lane) : (want << 48);
+                }
+            for (;;) {
+                bool stale = false;
+#pragma unroll
+                for (int it = 0; it < kMaxRT; ++it)
+#pragma unroll
+                    for (int q = 0; q < kMaxKS / 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if ((aw[it][q][e] >> 48) != want) {
+                                aw[it][q][e] = ld_w(in + ((size_t)(it * kMaxKS + wave + 4 * q) * 8 + e) * 64 + lane);
+                                stale = true;
+                            }
+                if (!__any(stale)) break;
+                if (wall_clock64() - t0 > 200000000ull || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bad_s = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
             // operand maps of v_mfma_f32_16x16x32: first = W rows (n = 16 jt + r16), second = activation rows
             // (m = r16), k = 8 kq .. 8 kq + 7 of the k-step; D column = lane & 15 = m, D rows 4 kq + reg = n
-            // two row tiles at a time: all their fragment loads are issued before the first multiply, so the
-            // tiles share one memory round trip (the loads are agent-scope atomics: the compiler keeps their order)
+            lf32x4 c[kMaxRT][2];
 #pragma unroll
-            for (int it0 = 0; it0 < kMaxRT; it0 += 2) {
-                if (it0 < RT) {
-                    uint4 af[2][kMaxKS / 4][3];
+            for (int it = 0; it < kMaxRT; ++it) {
+                c[it][0] = c[it][1] = lf32x4{0.f, 0.f, 0.f, 0.f};
+                if (it < nrt) {
 #pragma unroll
-                    for (int h = 0; h < 2; ++h)
+                    for (int q = 0; q < kMaxKS / 4; ++q) {
+                        if (wave + 4 * q < KS) {
+                            // 8 words -> the three limb fragments (8 bf16 each)
+                            unsigned hh[4], mm[4], ll[4];
 #pragma unroll
-                        for (int q = 0; q < kMaxKS / 4; ++q) {
-                            const int ks = wave + 4 * q;
-                            if (it0 + h < RT && ks < KS) {
-                                const uint4* a = actl[cur] + ((size_t)((it0 + h) * kMaxKS + ks) * 3) * 64 + lane;
-                                af[h][q][0] = ld_u4(a); af[h][q][1] = ld_u4(a + 64); af[h][q][2] = ld_u4(a + 128);
-                            } else {
-                                af[h][q][0] = af[h][q][1] = af[h][q][2] = make_uint4(0, 0, 0, 0);
+                            for (int e = 0; e < 4; ++e) {
+                                const unsigned lo0 = (unsigned)aw[it][q][2 * e], lo1 = (unsigned)aw[it][q][2 * e + 1];
+                                const unsigned hi0 = (unsigned)(aw[it][q][2 * e] >> 32), hi1 = (unsigned)(aw[it][q][2 * e + 1] >> 32);
+                                hh[e] = __builtin_amdgcn_perm(lo1, lo0, 0x05040100u);
+                                mm[e] = __builtin_amdgcn_perm(lo1, lo0, 0x07060302u);
+                                ll[e] = __builtin_amdgcn_perm(hi1, hi0, 0x05040100u);
                             }
-                        }
+                            const uint4 a0 = make_uint4(hh[0], hh[1], hh[2], hh[3]), a1 = make_uint4(mm[0], mm[1], mm[2], mm[3]),
+                                        a2 = make_uint4(ll[0], ll[1], ll[2], ll[3]);
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        if (it0 + h < RT) {
-                            lf32x4 c = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                            for (int q = 0; q < kMaxKS / 4; ++q) {
-                                if (wave + 4 * q < KS) {
-#define HD_MM(wv, av) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lbf16x8, wv), \
-                                                          __builtin_bit_cast(lbf16x8, av), c, 0, 0, 0);
-                                    HD_MM(wf[q][0], af[h][q][2]) HD_MM(wf[q][2], af[h][q][0]) HD_MM(wf[q][1], af[h][q][1])
-                                    HD_MM(wf[q][0], af[h][q][1]) HD_MM(wf[q][1], af[h][q][0]) HD_MM(wf[q][0], af[h][q][0])
+                            for (int jl = 0; jl < 2; ++jl) {
+                                if (jl < njl) {
+                                    lf32x4 cc = c[it][jl];
+#define HD_MM(wv, av) cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lbf16x8, wv), \
+                                                           __builtin_bit_cast(lbf16x8, av), cc, 0, 0, 0);
+                                    HD_MM(wf[jl][q][0], a2) HD_MM(wf[jl][q][2], a0) HD_MM(wf[jl][q][1], a1)
+                                    HD_MM(wf[jl][q][0], a1) HD_MM(wf[jl][q][1], a0) HD_MM(wf[jl][q][0], a0)
 #undef HD_MM
+                                    c[it][jl] = cc;
                                 }
                             }
-                            red[wave][it0 + h][lane] = make_float4(c[0], c[1], c[2], c[3]);
                         }
                     }
                 }
             }
+            __syncthreads();                                       // the previous layer's write-out has read red[]
+#pragma unroll
+            for (int it = 0; it < kMaxRT; ++it)
+#pragma unroll
+                for (int jl = 0; jl < 2; ++jl)
+                    red[wave][jl * kMaxRT + it][lane] = make_float4(c[it][jl][0], c[it][jl][1], c[it][jl][2], c[it][jl][3]);
+            // the next layer's weights: the registers are free, and the request has a whole hand-over to land
+            if (!last) load_w(ch.l[li + 1]);
             __syncthreads();
-            if (wave < RT) {                                       // wavefront `it` finishes row tile `it`
-                const int it = wave;
+            ok = ok && bad_s == 0;
+            if (fin) {                                             // this wavefront finishes output tile (jl_e, it_e)
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    const float4 p = red[w][it][lane];
+                    const float4 p = red[w][wave][lane];
                     v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
                 }
-                const int rl = it * 16 + r16, row = r0 + rl, nb = jt * 16 + 4 * kq;
-                const int64_t er = (L.add_emb && row < rows) ? emb_idx[row] : -1;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int n = nb + e;
                     float y = 0.f;
-                    if (n < L.N) {
-                        y = v[e] + (L.bias ? L.bias[n] : 0.f);
+                    if (nb_e + e < L.N) {
+                        y = v[e] + bq[e];
                         if (L.epi == 1) y = gelu_erfc(y);
-                        else if (L.epi == 2) y = ld_f(&actf[cur][(size_t)rl * kMaxW + n]) + gelu_erfc(y);
-                        if (er >= 0 && er < emb_rows) y += emb[er * (int64_t)L.N + n];
-                        else if (L.add_emb && row < rows) y = __builtin_nanf("");    // index out of range (nn.Embedding raises)
+                        else if (L.epi == 2) y = py[e] + gelu_erfc(y);
+                        y += eq[e];
+                        if (emb_bad) y = __builtin_nanf("");
                     }
                     v[e] = y;
+                    py[e] = y;
                 }
                 if (last) {
-                    if (row < rows) {
+                    if (row_e < rows) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (nb + e < L.N) out[(size_t)row * ldo + nb + e] = ok ? v[e] : __builtin_nanf("");
+                            if (nb_e + e < L.N) out[(size_t)row_e * ldo + nb_e + e] = ok ? v[e] : __builtin_nanf("");
                     }
                 } else {
-                    float* fo = actf[nxt] + (size_t)rl * kMaxW + nb;
-                    st_u2(fo, make_uint2(__float_as_uint(v[0]), __float_as_uint(v[1])));
-                    st_u2(fo + 2, make_uint2(__float_as_uint(v[2]), __float_as_uint(v[3])));
-                    // columns 16 jt .. + 15 = half a k-step of the next layer: lane (r16, 2 (jt & 1) + (kq >> 1)),
-                    // 8-byte half kq & 1
-                    unsigned hh[2], mm[2], ll[2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        hh[e] = limb_pk_bf16(v[2 * e], v[2 * e + 1]);
-                        const float q0 = v[2 * e] - limb_lo(hh[e]), q1 = v[2 * e + 1] - limb_hi(hh[e]);
-                        mm[e] = limb_pk_bf16(q0, q1);
-                        ll[e] = limb_pk_bf16(q0 - limb_lo(mm[e]), q1 - limb_hi(mm[e]));
-                    }
+                    // columns 16 jt + 4 kq .. + 3 = elements 4 (kq & 1) .. + 3 of lane (r16, 2 (jt & 1) + (kq >> 1)) of
+                    // k-step jt >> 1 of the next layer
+                    const int jt = 2 * g + jl_e;
+                    const unsigned tag = (unsigned)((epoch << 5) | (li + 1));
                     const int ln = r16 + 16 * (2 * (jt & 1) + (kq >> 1));
-                    uint2* o = reinterpret_cast<uint2*>(actl[nxt] + ((size_t)(it * kMaxKS + (jt >> 1)) * 3) * 64 + ln) + (kq & 1);
-                    st_u2(o, make_uint2(hh[0], hh[1]));
-                    st_u2(o + 2 * 64, make_uint2(mm[0], mm[1]));
-                    st_u2(o + 2 * 128, make_uint2(ll[0], ll[1]));
+                    u64* o = nxt + ((size_t)(it_e * kMaxKS + (jt >> 1)) * 8 + 4 * (kq & 1)) * 64 + ln;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) st_w(o + e * 64, make_word(v[e], tag));
                 }
             }
-            __syncthreads();                                       // red[] is free again
         }
-        if (!last) group_arrive(ctr);
+    }
+    // the last workgroup to leave advances the epoch (and zeroes the words when it wraps)
+    __syncthreads();
+    if (tid == 0) {
+        const int left = __hip_atomic_fetch_add(hdr + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = left == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last_s) {
+        const int done = hdr[0] + 1 == kEpochs ? 0 : hdr[0] + 1;
+        if (done == 0) {
+            for (size_t i = tid; i < kBufWords; i += blockDim.x) { st_w(buf0 + i, 0); st_w(buf1 + i, 0); }
+        }
+        __syncthreads();
+        if (tid == 0) { hdr[0] = done; hdr[1] = 0; }
     }
 }
 
@@ -316,7 +356,8 @@ extern "C" int hd_linear_chain_small_f32(const void* x, int64_t ldx, int64_t row
         HD_REQUIRE(a.d_in >= 1 && a.d_in <= kMaxW && a.d_out >= 1 && a.d_out <= kMaxW,
                    "hd_linear_chain_small_f32: layer %d wider than %d", i, kMaxW);
         HD_REQUIRE(a.epi >= 0 && a.epi <= 2, "hd_linear_chain_small_f32: layer %d: epilogue must be 0, 1 or 2", i);
-        HD_REQUIRE(a.epi != 2 || a.d_in == a.d_out, "hd_linear_chain_small_f32: layer %d: a residual layer keeps its width", i);
+        HD_REQUIRE(a.epi != 2 || (i >= 1 && a.d_in == a.d_out),
+                   "hd_linear_chain_small_f32: layer %d: a residual layer keeps its width and is not the first", i);
         HD_REQUIRE(i == 0 || a.d_in == layers[i - 1].d_out, "hd_linear_chain_small_f32: layer %d: d_in != previous d_out", i);
         HD_REQUIRE(i == n_layers - 1 || a.d_out % 32 == 0,
                    "hd_linear_chain_small_f32: layer %d: inner widths must be multiples of 32", i);
@@ -326,22 +367,18 @@ extern "C" int hd_linear_chain_small_f32(const void* x, int64_t ldx, int64_t row
     HD_REQUIRE(ldx >= layers[0].d_in && ldo >= layers[n_layers - 1].d_out, "hd_linear_chain_small_f32: leading dimension too small");
     HD_REQUIRE(!any_emb || (emb && emb_idx && emb_rows >= 1), "hd_linear_chain_small_f32: embedding table / indices missing");
     char* p = (char*)workspace;
-    Ws ws;
-    ws.ctr = (int*)p;
-    ws.fail = (int*)(p + 128);
-    ws.actl[0] = (uint4*)(p + 256);
-    ws.actl[1] = (uint4*)(p + 256 + kActlBytes);
-    ws.actf[0] = (float*)(p + 256 + 2 * kActlBytes);
-    ws.actf[1] = (float*)(p + 256 + 2 * kActlBytes + kActfBytes);
-    hipError_t e = hipMemsetAsync(workspace, 0, 256, (hipStream_t)st);
+    int* hdr = (int*)p;
+    u64* buf0 = (u64*)(p + 256);
+    u64* buf1 = buf0 + kBufWords;
+    hipError_t e = hipMemsetAsync(p + 128, 0, 4, (hipStream_t)st);          // the fail flag
     if (e != hipSuccess) { set_error("hd_linear_chain_small_f32: hipMemsetAsync: %s", hipGetErrorString(e)); return HD_EHIP; }
-    // rows per group: a multiple of 16, at most kMaxRT tiles
-    int rg = (int)((rows + kGroups * 16 - 1) / (kGroups * 16)) * 16;
+    // row tiles per group: 1 up to 256 rows, 2 beyond
+    int RT = (int)(((rows + 15) / 16 + kGroups - 1) / kGroups);
     const float* xp = (const float*)x;
     const float* ep = (const float*)emb;
     float* op = (float*)out;
     int rows_i = (int)rows, emb_rows_i = (int)(emb_rows < 0x7fffffff ? emb_rows : 0x7fffffff);
-    void* args[] = {&xp, &ldx, &rows_i, &ch, &ep, &emb_idx, &emb_rows_i, &op, &ldo, &ws, &rg};
+    void* args[] = {&xp, &ldx, &rows_i, &ch, &ep, &emb_idx, &emb_rows_i, &op, &ldo, &hdr, &buf0, &buf1, &RT};
     e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(linear_chain_small), dim3(kGroups * kG), dim3(256), args,
                                    0, (hipStream_t)st);
     if (e != hipSuccess) {
@@ -351,7 +388,7 @@ extern "C" int hd_linear_chain_small_f32(const void* x, int64_t ldx, int64_t row
     return HD_OK;
 }
 
-// 1 after a launch whose group barrier timed out (its outputs are NaN); reads the workspace (synchronises the stream)
+// 1 after a launch in which a wait timed out (its outputs are NaN); reads the workspace (synchronises the stream)
 extern "C" int hd_chain_failed(const void* workspace, void* st) {
     int f = 0;
     if (!workspace) return 0;

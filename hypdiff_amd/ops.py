@@ -515,7 +515,7 @@ def chain_small_ok(x, layers):
     widths multiples of 32, fp32-faithful limb arithmetic allowed (GEMM_MODE "exact" keeps the per-layer exact GEMMs)."""
     if _NO_CHAIN_SMALL or GEMM_MODE == "exact" or x.dtype != torch.float32 or x.dim() != 2:
         return False
-    if not (0 < x.shape[0] <= CHAIN_SMALL_MAX_ROWS) or len(layers) > 32:
+    if not (0 < x.shape[0] <= CHAIN_SMALL_MAX_ROWS) or len(layers) > 31 or layers[0][2] == 2:
         return False
     for i, (w, b, epi) in enumerate(layers):
         n, k = w.shape
@@ -540,7 +540,8 @@ def linear_chain_small(x, layers, emb_after=None, emb=None, emb_idx=None):
     key = (x.device.index, torch.cuda.current_stream().cuda_stream)
     ws = _chain_ws.get(key)
     if ws is None:
-        ws = _chain_ws[key] = torch.empty(_lib.load().hd_chain_workspace_bytes() // 4, dtype=torch.int32, device=x.device)
+        # zero-filled once: the kernel's tagged words start from "never valid" (csrc/chain_small.hip)
+        ws = _chain_ws[key] = torch.zeros(_lib.load().hd_chain_workspace_bytes() // 4, dtype=torch.int32, device=x.device)
     out = torch.empty(n, layers[-1][0].shape[0], dtype=torch.float32, device=x.device)
     tab = None if emb is None else emb.detach()
     _lib.call("hd_linear_chain_small_f32", _p(x), x.stride(0), n, arr, len(layers), _p(tab), _p(emb_idx),

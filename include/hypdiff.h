@@ -264,13 +264,14 @@ int hd_limb_pack_f32(const void* in, int64_t ld, int64_t rows, int64_t cols, voi
 int hd_limb_unpack_f32(const void* in, int64_t rows, int64_t cols, void* out, int64_t ld, void* stream);
 /* A stack of nn.Linear layers on a small batch (rows <= 512, widths <= 512) in ONE cooperative launch: MLP.forward /
  * Backbone.forward of ddpm.py:9-41 (config 3: 24 layers of width 512 at B = 200).  Layer i: y = x W_i^T + bias_i, then
- * epi 0 nothing, 1 erf-GELU, 2 x + GELU(y) (ddpm.py:20-22; d_in == d_out); add_emb != 0: y += emb[emb_idx[row]]
+ * epi 0 nothing, 1 erf-GELU, 2 x + GELU(y) (ddpm.py:20-22; d_in == d_out, not the first layer); add_emb != 0: y += emb[emb_idx[row]]
  * afterwards (ddpm.py:39, emb (emb_rows, d_out) fp32 contiguous; an index outside [0, emb_rows) gives a NaN row).  wimg
  * = hd_chain_pack_w_f32 of W_i (d_out, d_in) fp32 row-major, hd_chain_image_bytes(d_out, d_in) bytes, 16-byte aligned;
  * inner widths are multiples of 32.  Arithmetic as hd_gemm_limbs_f32 (3 bf16 limbs, fp32-faithful).  workspace:
- * hd_chain_workspace_bytes() bytes of device memory, 16-byte aligned, private to the call while it runs.  The launch
+ * hd_chain_workspace_bytes() bytes of device memory, 16-byte aligned, ZERO-FILLED ONCE by the caller when it is
+ * allocated and from then on only passed to this function, private to the call while it runs (at most 31 layers).  The launch
  * is cooperative (hipLaunchCooperativeKernel: 256 workgroups resident at once); hd_chain_failed(workspace, stream)
- * returns 1 if a group barrier of the last launch timed out (outputs are NaN then) -- it synchronises the stream. */
+ * returns 1 if a wait of the last launch timed out (outputs are NaN then) -- it synchronises the stream. */
 typedef struct {
     const void* wimg;
     const void* bias;

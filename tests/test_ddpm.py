@@ -147,10 +147,11 @@ def test_linear_chain_small_shapes():
     from hypdiff_amd import ops
     rs = np.random.RandomState(5)
     for rows, dims, epis in [(200, [64, 512, 512, 64], [1, 2, 0]), (33, [7, 32, 32, 5], [1, 2, 0]),
-                             (512, [96, 96, 160, 3], [2, 1, 0]), (16, [512, 512], [2]), (5, [20, 13], [0])]:
+                             (512, [96, 96, 96, 160, 3], [1, 2, 1, 0]), (16, [512, 512, 512], [0, 2]), (5, [20, 13], [0]),
+                             (257, [33, 64, 64], [1, 2])]:
         ws = [torch.from_numpy((rs.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32)).cuda()
               for i in range(len(epis))]
-        bs = [None if i == 1 else torch.from_numpy(rs.standard_normal(dims[i + 1]).astype(np.float32)).cuda()
+        bs = [None if i == 2 else torch.from_numpy(rs.standard_normal(dims[i + 1]).astype(np.float32)).cuda()
               for i in range(len(epis))]
         x = torch.from_numpy(rs.standard_normal((rows, dims[0])).astype(np.float32)).cuda()
         layers = list(zip(ws, bs, epis))
@@ -161,6 +162,14 @@ def test_linear_chain_small_shapes():
             z = h @ w.double().cpu().T + (0 if b is None else b.double().cpu())
             h = z if e == 0 else (torch.nn.functional.gelu(z) if e == 1 else h + torch.nn.functional.gelu(z))
         assert_close(got.cpu().numpy(), h.numpy(), what=f"chain {rows} x {dims}", atol_scale=3e-6)
-    assert not ops.chain_small_ok(torch.zeros(513, 64, device="cuda"), layers)
+    assert not ops.chain_small_ok(torch.zeros(513, 33, device="cuda"), layers)
+    assert not ops.chain_small_ok(x, [(ws[1], bs[1], 2)])            # a residual first layer keeps the launch-per-layer path
+    # 2100 launches on one workspace: the tag epoch wraps (2046) and the words are zeroed by the kernel itself
+    want = ops.linear_chain_small(x, layers)
+    for _ in range(2100):
+        got = ops.linear_chain_small(x, layers)
+    assert torch.equal(got, want)
+    wsb = ops._chain_ws[(x.device.index, torch.cuda.current_stream().cuda_stream)]
+    assert ops._lib.load().hd_chain_failed(ops._p(wsb), ops._stream()) == 0
     with pytest.raises(RuntimeError, match="rows must be"):
         ops._lib.call("hd_linear_chain_small_f32", None, 64, 513, None, 1, None, None, 0, None, 64, None, 0, ops._stream())

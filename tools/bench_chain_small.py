@@ -39,5 +39,22 @@ def main():
         print(f"B={B}: one launch {t1:7.1f} us | launch per layer {t2:7.1f} us", flush=True)
 
 
+def depth_sweep():
+    """time against the number of layers: slope = cost of one layer hand-over, intercept = launch"""
+    torch.manual_seed(0)
+    ws = [torch.randn(512, 512, device="cuda") / 512 ** 0.5 for _ in range(24)]
+    bs = [torch.randn(512, device="cuda") for _ in range(24)]
+    for B in (16, 200):
+        x = torch.randn(B, 512, device="cuda")
+        line = []
+        for n in (1, 2, 4, 8, 16, 24):
+            layers = [(ws[i], bs[i], 1 if i == 0 else 2) for i in range(n)]
+            line.append(f"{n}: {timeit(lambda: ops.linear_chain_small(x, layers)):6.1f}")
+        print(f"B={B} layers -> us  " + " | ".join(line), flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "depth":
+        depth_sweep()
+    else:
+        main()
