@@ -370,8 +370,7 @@ extern "C" int hd_linear_chain_small_f32(const void* x, int64_t ldx, int64_t row
     int* hdr = (int*)p;
     u64* buf0 = (u64*)(p + 256);
     u64* buf1 = buf0 + kBufWords;
-    hipError_t e = hipMemsetAsync(p + 128, 0, 4, (hipStream_t)st);          // the fail flag
-    if (e != hipSuccess) { set_error("hd_linear_chain_small_f32: hipMemsetAsync: %s", hipGetErrorString(e)); return HD_EHIP; }
+    hipError_t e;
     // row tiles per group: 1 up to 256 rows, 2 beyond
     int RT = (int)(((rows + 15) / 16 + kGroups - 1) / kGroups);
     const float* xp = (const float*)x;
@@ -389,10 +388,14 @@ extern "C" int hd_linear_chain_small_f32(const void* x, int64_t ldx, int64_t row
 }
 
 // 1 after a launch in which a wait timed out (its outputs are NaN); reads the workspace (synchronises the stream)
-extern "C" int hd_chain_failed(const void* workspace, void* st) {
+extern "C" int hd_chain_failed(void* workspace, void* st) {
     int f = 0;
     if (!workspace) return 0;
     if (hipMemcpyAsync(&f, (const char*)workspace + 128, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)st) != hipSuccess) return -1;
     if (hipStreamSynchronize((hipStream_t)st) != hipSuccess) return -1;
+    if (f != 0) {                                              // the flag is sticky: reading it clears it
+        if (hipMemsetAsync((char*)workspace + 128, 0, 4, (hipStream_t)st) != hipSuccess) return -1;
+        if (hipStreamSynchronize((hipStream_t)st) != hipSuccess) return -1;
+    }
     return f;
 }

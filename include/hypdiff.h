@@ -271,7 +271,8 @@ int hd_limb_unpack_f32(const void* in, int64_t rows, int64_t cols, void* out, in
  * hd_chain_workspace_bytes() bytes of device memory, 16-byte aligned, ZERO-FILLED ONCE by the caller when it is
  * allocated and from then on only passed to this function, private to the call while it runs (at most 31 layers).  The launch
  * is cooperative (hipLaunchCooperativeKernel: 256 workgroups resident at once); hd_chain_failed(workspace, stream)
- * returns 1 if a wait of the last launch timed out (outputs are NaN then) -- it synchronises the stream. */
+ * returns 1 if a wait of any launch since the last query timed out (outputs are NaN then) and clears the flag -- it
+ * synchronises the stream. */
 typedef struct {
     const void* wimg;
     const void* bias;
@@ -283,7 +284,7 @@ int hd_chain_pack_w_f32(const void* W, int64_t ld, int64_t d_out, int64_t d_in, 
 int hd_linear_chain_small_f32(const void* x, int64_t ldx, int64_t rows, const hd_chain_layer* layers, int n_layers,
                               const void* emb, const int64_t* emb_idx, int64_t emb_rows, void* out, int64_t ldo,
                               void* workspace, int64_t workspace_bytes, void* stream);
-int hd_chain_failed(const void* workspace, void* stream);
+int hd_chain_failed(void* workspace, void* stream);
 
 /* One-pass producers of bf16x3 GEMM operands (no fp32 staging copy, one read of the rows): cat(x.float(),
  * t[:,None]) of models/direction_diffusion.py:57-58 (x f32/f64 by x_dtype 0/1, t as in hd_mlp_pack_input;
