@@ -47,6 +47,16 @@ __device__ __forceinline__ void agg_epilogue(TL& acc, int epi, const Curv& cin, 
     if (epi == E_AGG_ACT) hyp_act<M, T>(acc, cin, cout, act);   // :170-173
 }
 
+// lane k's value of v, k wavefront-uniform
+__device__ __forceinline__ float wave_get(float v, int k) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
+}
+__device__ __forceinline__ double wave_get(double v, int k) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, k), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), k);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 // acc += sum over entries [k0, k1) read through (cols, vals) with index offset `off`
 template <typename T, int DEPTH, class TL, class CI, class VI>
 __device__ __forceinline__ void gather_accumulate(TL& acc, const T* __restrict__ x, int d, int64_t ldx, int k0, int k1,
@@ -86,6 +96,28 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 ? 4 : 1)) void spmm_rows(co
     TL acc;
     acc.init(d);
     const int64_t nblk = (n + RPB - 1) / RPB;
+    if constexpr (G == 64) {
+        // one wavefront per row: its neighbour list goes through the wavefront's own registers (lane k holds entry
+        // k of a 64-entry window, handed out with v_readlane) -- no LDS stage, no workgroup barrier, so the four
+        // wavefronts of a block run their rows independently (the barrier pair cost the short rows of the graph-set
+        // workloads more than the gather itself)
+        const int lane = threadIdx.x & 63;
+        for (int64_t row = (int64_t)blockIdx.x * RPB + (threadIdx.x >> 6); row < n; row += (int64_t)gridDim.x * RPB) {
+            const int rs = rowptr[row], re = rowptr[row + 1];
+            if (skip_long && re - rs > kLongRow) continue;
+            acc.zero();
+            for (int base = rs; base < re; base += 64) {
+                const int cnt = re - base < 64 ? re - base : 64;
+                const int32_t c_l = lane < cnt ? col[base + lane] : 0;
+                const T v_l = lane < cnt ? val[base + lane] : T(0);
+                gather_accumulate<T, DEPTH>(acc, x, d, ldx, 0, cnt, [&](int k) { return __builtin_amdgcn_readlane(c_l, k); },
+                                            [&](int k) { return wave_get(v_l, k); });
+            }
+            agg_epilogue<M, T>(acc, epi, cin, cout, act);
+            acc.store(out + row * ldo);
+        }
+        return;
+    }
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const int64_t r0 = blk * RPB;
         const int64_t r1 = r0 + RPB < n ? r0 + RPB : n;
