@@ -90,6 +90,7 @@ SIGNATURES = {
     "hd_limb_pack_f32": [P, I64, I64, I64, P, P],
     "hd_limb_unpack_f32": [P, I64, I64, P, I64, P],
     "hd_gemm_limbs_f32": [P, P, P, P, P, P, I64, I64, I64, I64, c_int, P],
+    "hd_gemm_limbs_train_f32": [P, P, P, P, P, P, P, I64, I64, I64, I64, c_int, P],
     "hd_mlp_pack_input_bf16x3": [P, c_int, P, c_int, c_double, P, I64, I64, P],
     "hd_row_pack_bf16x3_f32": [P, c_int, HdCurv, P, P, I64, I64, P],
     "hd_limb_pack_f16x2_f32": [P, I64, I64, I64, P, P, P, P],

@@ -98,6 +98,38 @@ def colsum(x, out=None):
     return out
 
 
+def gemm_limbs_train(a, w, bias, aux, epi, want_z=False, want_f32=True, want_limbs=False):
+    """hd_gemm_limbs_train_f32 on bf16x3 limb images: returns (z, c, cl).  Forward (epi 0 / 1): z = a w^T + bias
+    (kept for the backward pass), c / cl = the activated value as fp32 / as the next layer's operand image.
+    Backward (epi 3): a = image of dz, w = image of W^T, aux = z of the layer below: c / cl = (dz W) * gelu'(aux)."""
+    M, K, N = a.rows, a.cols, w.rows
+    assert w.cols == K, ((a.rows, a.cols), (w.rows, w.cols))
+    dev = a.buf.device
+    z = torch.empty(M, N, dtype=torch.float32, device=dev) if want_z else None
+    c = torch.empty(M, N, dtype=torch.float32, device=dev) if want_f32 else None
+    cl = ops.limb_empty(M, N, dev, "bf16x3") if want_limbs else None
+    assert aux is None or (aux.is_contiguous() and tuple(aux.shape) == (M, N))
+    ev = ops.GEMM_EVENTS
+    if ev is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.call("hd_gemm_limbs_train_f32", ops._p(a.buf), ops._p(w.buf), ops._p(bias), ops._p(aux), ops._p(z), ops._p(c),
+              ops._p(cl.buf) if cl is not None else None, M, N, K, N, epi, ops._stream())
+    if ev is not None:
+        e1.record()
+        kp, npad = (K + 31) // 32 * 32, (N + 31) // 32 * 32
+        ev.append((e0, e1, 2.0 * M * N * K, 6.0 * (M * kp + N * kp) + 4.0 * M * N * ((z is not None) + (c is not None)
+                   + (aux is not None)) + (6.0 * M * npad if cl is not None else 0.0), "gemm_limbs"))
+    return z, c, cl
+
+
+def _limb_stack_ok(x, kinds, ws_):
+    """The stack can run on the persistent limb GEMM: fp32-faithful limb arithmetic allowed (not GEMM_MODE "exact"),
+    no residual layers (the mlp denoiser: GELU ... GELU, LIN), rows of 16-byte multiples, no gradient for x."""
+    return (ops.GEMM_MODE != "exact" and not x.requires_grad and all(k in (GELU, LIN) for k in kinds) and kinds[-1] == LIN
+            and x.shape[0] > 0 and all(w.shape[0] % 4 == 0 for w in ws_))
+
+
 class LinearStack(torch.autograd.Function):
     """y = stack(x): layer l computes z = x_l W_l^T + b_l and x_{l+1} = z (LIN), gelu(z)
     (GELU) or x_l + gelu(z) (RES).  `x` is a contiguous fp32 (M, K0) tensor with K0 % 4 == 0;
@@ -109,6 +141,28 @@ class LinearStack(torch.autograd.Function):
         ops._dev(x)
         ws_, bs_ = params[0::2], params[1::2]
         assert len(ws_) == len(kinds) == len(bs_)
+        ctx.limbs = _limb_stack_ok(x, kinds, ws_)
+        if ctx.limbs:
+            # operands travel as bf16x3 limb images (split once per element by the producing GEMM's write-out);
+            # fp32 copies are written where the backward pass reads them: z (gelu') and x_l (weight gradient)
+            xs, zs = [x], []
+            a = ops.limb_pack(x[:, : ws_[0].shape[1]], "bf16x3")
+            h = x
+            for l, kind in enumerate(kinds):
+                last = l == len(kinds) - 1
+                wl, _ = ops.weight_limbs(ws_[l], "bf16x3")
+                z, h, a = gemm_limbs_train(a, wl, bs_[l].detach(), None, 1 if kind == GELU else 0, want_z=kind == GELU,
+                                           want_limbs=not last)
+                zs.append(z)
+                if not last:
+                    xs.append(h)
+            ctx.kinds = kinds
+            ctx.params = params
+            ctx.need_x = False
+            ctx.wshapes = [tuple(w.shape) for w in ws_]
+            ctx.save_for_backward(*xs, *[z for z in zs if z is not None], *[w.detach() for w in ws_])
+            ctx.nz = [z is not None for z in zs]
+            return h
         xs, zs, wpad = [], [], []
         h = x
         for l, kind in enumerate(kinds):
@@ -170,6 +224,14 @@ class LinearStack(torch.autograd.Function):
                 grads[2 * l + 1] = colsum(dz)
             if l == 0 and not ctx.need_x:
                 break
+            if ctx.limbs:
+                # dz_below = (dz @ W_l) * gelu'(z_below) on the limb GEMM: dz as an image (the one below is written
+                # by this launch's write-out), W_l^T split once per step
+                if l == top:
+                    dz_img = ops.limb_pack(dz, "bf16x3")
+                wt_img = ops.limb_pack(transpose(w), "bf16x3")
+                _, dz, dz_img = gemm_limbs_train(dz_img, wt_img, None, zs[l - 1], 3, want_limbs=l - 1 >= 1)
+                continue
             wt = transpose(w)                                    # (K_l, N_l): contraction over N_l
             M, Kl = x_l.shape
             resid = g_up if kinds[l] == RES else None

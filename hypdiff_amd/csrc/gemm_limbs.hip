@@ -376,8 +376,32 @@ struct Scales {
 template <bool F16, bool CHECK>
 __device__ __forceinline__ void store_quad(float v[4], int m, int mloc, int nb, int half, int N, int nout, int ldc,
                                            int epi, bool vec, const float* __restrict__ resid, float* __restrict__ C,
-                                           uint4* __restrict__ CL, size_t cl_tile_base, int eo_m, float& rmax) {
-    if (epi != 0) {
+                                           uint4* __restrict__ CL, size_t cl_tile_base, int eo_m, float& rmax,
+                                           float* __restrict__ Z = nullptr) {
+    if (Z) {                                                  // training: the pre-activation is kept for the backward pass
+        float* zo = Z + (size_t)m * ldc + nb;
+        if (vec && (!CHECK || nb + 3 < N)) {
+            *reinterpret_cast<float4*>(zo) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (!CHECK || nb + e < N) zo[e] = v[e];
+        }
+    }
+    if (epi == 3) {                                           // backward: dz_below = g * gelu'(z_below), z_below = resid
+        const float* rp = resid + (size_t)m * ldc + nb;
+        float r[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vec && (!CHECK || nb + 3 < N)) {
+            const float4 q = *reinterpret_cast<const float4*>(rp);
+            r[0] = q.x; r[1] = q.y; r[2] = q.z; r[3] = q.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (!CHECK || nb + e < N) r[e] = rp[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(r[e]);
+    } else if (epi != 0) {
         float r[4] = {0.f, 0.f, 0.f, 0.f};
         if (epi == 2) {
             const float* rp = resid + (size_t)m * ldc + nb;
@@ -445,7 +469,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
                                                   const float* __restrict__ bias, const float* __restrict__ resid,
                                                   float* __restrict__ C, uint4* __restrict__ CL, int M, int N,
                                                   int nslab, int ldc, int epi, int tiles_m, int tiles_n,
-                                                  int nslab_out, Scales sc, int phase_mode, int delay_ticks) {
+                                                  int nslab_out, Scales sc, int phase_mode, int delay_ticks,
+                                                  float* __restrict__ Z) {
     constexpr int L = kLimbs<F16>, kTile = kTileOf<F16>;
     constexpr int WCN = WAVES / 2;               // wavefronts are laid out 2 (rows) x WCN (columns)
     constexpr int WCOLS = BNT / WCN;             // columns per wavefront: 32 or 64
@@ -486,7 +511,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
     const int nout = nslab_out * 32;                      // limb image width: zeros from N up to here
     // fp32 rows of C / resid: every 4-column quad is 16-byte aligned (quads start at multiples of 4)
     const bool vec = (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
-                     (reinterpret_cast<uintptr_t>(resid) & 15) == 0;
+                     (reinterpret_cast<uintptr_t>(resid) & 15) == 0 && (reinterpret_cast<uintptr_t>(Z) & 15) == 0;
     // operand maps of v_mfma_f32_16x16x32: lane (r16 = lane&15, kq = lane>>4) supplies row r16,
     // k = 8 kq .. 8 kq + 7 of the slab = chunk kc = kq.  First operand = W rows (n), second = A rows
     // (m): the accumulator is the C^T tile, D column = lane&15 = m, D rows 4 kq + reg = n.
@@ -623,7 +648,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
                             v[e] += bq[j][e];
                         }
                         store_quad<F16, CHECK>(v, m, mloc, nb, kq & 1, N, nout, ldc, epi, vec, resid, C, CL, cl_base,
-                                               eo_m, rmax);
+                                               eo_m, rmax, Z);
                     }
                     if constexpr (F16) {
                         if (sc.amax_o) {                            // the 4 lanes of a row sit 16 apart
@@ -688,7 +713,7 @@ int unpack_impl(const char* who, const void* in, const void* ex, int64_t rows, i
 
 template <bool F16>
 int gemm_impl(const char* who, const void* A, const void* W, const void* bias, const void* resid, void* C, void* CL,
-              int64_t M, int64_t N, int64_t K, int64_t ldc, int epi, Scales sc, void* st) {
+              int64_t M, int64_t N, int64_t K, int64_t ldc, int epi, Scales sc, void* st, void* Z = nullptr) {
     HD_REQUIRE(M >= 0 && N >= 1 && K >= 1, "%s: bad shape M=%lld N=%lld K=%lld", who, (long long)M, (long long)N,
                (long long)K);
     if (M == 0) return HD_OK;
@@ -696,8 +721,8 @@ int gemm_impl(const char* who, const void* A, const void* W, const void* bias, c
     HD_REQUIRE(is_aligned16(A) && is_aligned16(W) && (!CL || is_aligned16(CL)),
                "%s: limb images must be 16-byte aligned", who);
     HD_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), "%s: size exceeds int32", who);
-    HD_REQUIRE(epi >= 0 && epi <= (F16 ? 1 : 2) && (epi != 2 || resid), "%s: bad epilogue / missing residual", who);
-    HD_REQUIRE((!C && epi != 2) || ldc >= N, "%s: leading dimension too small", who);
+    HD_REQUIRE(epi >= 0 && epi <= (F16 ? 1 : 3) && (epi < 2 || resid), "%s: bad epilogue / missing residual", who);
+    HD_REQUIRE((!C && !Z && epi < 2) || ldc >= N, "%s: leading dimension too small", who);
     if (F16) {
         HD_REQUIRE(sc.ea && sc.ew, "%s: null row exponents", who);
         HD_REQUIRE(!CL || (sc.amax_a && sc.eo), "%s: a limb-image output needs amax_a and eo", who);
@@ -748,7 +773,7 @@ int gemm_impl(const char* who, const void* A, const void* W, const void* bias, c
         gemm_limbs<BNT_, WAVES_, F16><<<dim3((unsigned)grid), dim3(WAVES_ * 64), 0, (hipStream_t)st>>>(    \
             (const uint4*)A, (const uint4*)W, (const float*)bias, (const float*)resid, (float*)C, (uint4*)CL,  \
             (int)M, (int)N, nslab, (int)ldc, epi, tiles_m, tiles_n, nslab_out, sc,                         \
-            grid < ntiles ? knobs.phase : 0, (int)((int64_t)knobs.delay_ns * nslab / 10));                 \
+            grid < ntiles ? knobs.phase : 0, (int)((int64_t)knobs.delay_ns * nslab / 10), (float*)Z);      \
     }
     if (cfg == 'W') HD_LAUNCH(128, 4, (F16 ? 2 : 1))
     else if (cfg == 'X') HD_LAUNCH(128, 8, (F16 ? 2 : 1))
@@ -888,7 +913,13 @@ extern "C" int hd_limb_unpack_f16x2_f32(const void* in, const void* ex, int64_t 
 
 extern "C" int hd_gemm_limbs_f32(const void* A, const void* W, const void* bias, const void* resid, void* C,
                                  void* CL, int64_t M, int64_t N, int64_t K, int64_t ldc, int epi, void* st) {
+    HD_REQUIRE(epi >= 0 && epi <= 2, "hd_gemm_limbs_f32: bad epilogue");
     return gemm_impl<false>("hd_gemm_limbs_f32", A, W, bias, resid, C, CL, M, N, K, ldc, epi, Scales{}, st);
+}
+extern "C" int hd_gemm_limbs_train_f32(const void* A, const void* W, const void* bias, const void* aux, void* Z, void* C,
+                                       void* CL, int64_t M, int64_t N, int64_t K, int64_t ldc, int epi, void* st) {
+    HD_REQUIRE(epi == 0 || epi == 1 || epi == 3, "hd_gemm_limbs_train_f32: epilogue must be 0, 1 or 3");
+    return gemm_impl<false>("hd_gemm_limbs_train_f32", A, W, bias, aux, C, CL, M, N, K, ldc, epi, Scales{}, st, Z);
 }
 extern "C" int hd_gemm_f16x2_f32(const void* A, const void* ea, const void* amax_a, const void* W, const void* ew,
                                  const void* bias, void* C, void* CL, void* eo, void* amax_o, int64_t M, int64_t N,

@@ -259,6 +259,12 @@ int hd_gemm_f32_bf16x3(const void* A, const void* W, const void* bias, const voi
  * of an (M,N) matrix (CL) that the next layer consumes directly; epi 0 none, 1 erf-GELU,
  * 2 resid + GELU (resid fp32 row-major, ldc).  Staging is a linear LDS-DMA copy; no split work
  * inside the contraction.  Same reference lines as hd_gemm_f32. */
+/* The training forms of the same kernel (autograd of diff.py:113-118 over models/direction_diffusion.py:56-69; the
+ * reference has no kernel of its own here).  Forward (epi 0 / 1): Z (optional, fp32 row-major, ldc) receives the
+ * pre-activation A W^T + bias, C / CL the activated value.  Backward (epi 3): A = limb image of dz (M, N_l), W = limb
+ * image of W_l^T (K_l, N_l), aux = z of the layer below (fp32, ldc): C / CL = (dz W_l) * gelu'(z_below). */
+int hd_gemm_limbs_train_f32(const void* A, const void* W, const void* bias, const void* aux, void* Z, void* C, void* CL,
+                            int64_t M, int64_t N, int64_t K, int64_t ldc, int epi, void* stream);
 int64_t hd_limb_image_bytes(int64_t rows, int64_t cols);
 int hd_limb_pack_f32(const void* in, int64_t ld, int64_t rows, int64_t cols, void* out, void* stream);
 int hd_limb_unpack_f32(const void* in, int64_t rows, int64_t cols, void* out, int64_t ld, void* stream);
