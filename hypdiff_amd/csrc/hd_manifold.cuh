@@ -282,6 +282,56 @@ __device__ __forceinline__ void hyp_act_homog(HB<T>*, TL& r, const Curv& cin, co
     r.set_first(t0);
 }
 
+// HypAgg's whole tail for a positively homogeneous activation, as ONE factor: expmap0(c_in) -> proj ->
+// HypAct(c_in, c_out) of a tangent row u with s = |u|^2 and sr = |act(u)|^2 (spatial part on the hyperboloid)
+// is f * act(u), time coordinate t0 (hyperboloid).  Every intermediate norm follows analytically from s and sr
+// (|g u| = g |u| for the positive factors g: rounding-level difference against re-measuring the row, as in
+// hyp_act_homog); same clamp order as expmap0 / proj / hyp_act_homog above.  Scalars only, so a wavefront can
+// evaluate it for several rows at once, one row per lane.
+template <typename T>
+__device__ __forceinline__ void agg_act_scalars(PB<T>*, T s, T sr, const Curv& cin, const Curv& cout, T& f, T& t0) {
+    const T sci = (T)cin.sc, sco = (T)cout.sc;
+    const T n0 = hd_sqrt(s);
+    const T n = clamp_min(n0, (T)kMinNorm);
+    const T fe = tanh15(sci * n) / (sci * n);                              // expmap0 (poincare.py:73-77)
+    const T np = clamp_min(fe * n0, (T)kMinNorm);
+    const T maxi = (T)((1.0 - Lim<T>::pb_eps) / cin.sc);
+    const T g = np > maxi ? fe * (maxi / np) : fe;                         // proj (:42-47)
+    const T n1 = clamp_min(g * n0, (T)kMinNorm);
+    const T f1 = fast_div((T)(1.0 / cin.sc) * artanh_ref(sci * n1), n1);   // logmap0 (:79-83)
+    const T m = f1 * g * fast_sqrt(sr);                                    // |act(logmap0(.))|
+    const T n2 = clamp_min(m, (T)kMinNorm);
+    const T f2 = fast_div(tanh15(sco * n2), sco * n2);                     // expmap0
+    const T n3 = clamp_min(f2 * m, (T)kMinNorm);
+    const T maxo = (T)((1.0 - Lim<T>::pb_eps) / cout.sc);
+    const T f3 = n3 > maxo ? fast_div(maxo, n3) : T(1);                    // proj
+    f = g * f1 * f2 * f3;
+    t0 = T(0);
+}
+template <typename T>
+__device__ __forceinline__ void agg_act_scalars(HB<T>*, T s, T sr, const Curv& cin, const Curv& cout, T& f, T& t0) {
+    const T sKi = (T)cin.sK, sKo = (T)cout.sK;
+    const T n0 = hd_sqrt(s);
+    const T n = clamp_min(n0, (T)kMinNorm);
+    T shv, chv;
+    sinhcosh15(n / sKi, shv, chv);                                         // expmap0 (hyperboloid.py:90-101)
+    const T fe = sKi * shv / n;
+    const T m1 = fe * n0;
+    const T x0 = hd_sqrt(clamp_min((T)cin.K + m1 * m1, (T)Lim<T>::hb_eps)); // proj (:43-52)
+    const T n1 = clamp_min(m1, (T)kMinNorm);
+    const T theta = clamp_min(x0 / sKi, (T)(1.0 + Lim<T>::hb_eps));
+    const T f1 = fast_div(sKi * arcosh_ref(theta), n1);                    // logmap0 (:103-113)
+    const T m = f1 * fe * fast_sqrt(sr);
+    const T n2 = clamp_min(m, (T)kMinNorm);
+    sinhcosh15(n2 * (T)(1.0 / cout.sK), shv, chv);                         // expmap0
+    const T f2 = fast_div(sKo * shv, n2);
+    const T ns = f2 * m;
+    t0 = hd_sqrt(clamp_min((T)cout.K + ns * ns, (T)Lim<T>::hb_eps));       // proj
+    f = fe * f1 * f2;
+}
+template <typename T> struct IsHB { static constexpr bool value = false; };
+template <typename T> struct IsHB<HB<T>> { static constexpr bool value = true; };
+
 // layers/hyp_layers.py:170-173: logmap0(c_in) -> act -> proj_tan0 -> expmap0(c_out) -> proj(c_out)
 template <class M, typename T, class TL>
 __device__ __forceinline__ void hyp_act(TL& r, const Curv& cin, const Curv& cout, int act) {

@@ -102,6 +102,52 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 ? 4 : 1)) void spmm_rows(co
         // wavefronts of a block run their rows independently (the barrier pair cost the short rows of the graph-set
         // workloads more than the gather itself)
         const int lane = threadIdx.x & 63;
+        if (sizeof(T) == 4 && epi == E_AGG_ACT && (act == ACT_IDENTITY || act == ACT_RELU || act == ACT_LEAKY_RELU)) {
+            // fused aggregate + HypAct, four rows per wavefront: the tail's scalar chain (sinh / cosh / arcosh or
+            // tanh / artanh, ~150 quarter-rate issues) is wavefront-uniform in the one-row form, i.e. computed 64
+            // times over; here lane r evaluates it for row r from the two row sums and hands the factor back
+            constexpr int R = 4;
+            const T slope = act == ACT_IDENTITY ? T(1) : (act == ACT_RELU ? T(0) : T(0.01));
+            for (int64_t row0 = ((int64_t)blockIdx.x * RPB + (threadIdx.x >> 6)) * R; row0 < n;
+                 row0 += (int64_t)gridDim.x * RPB * R) {
+                TL a4[R];
+                bool ok4[R];
+                T s_l = T(0), sr_l = T(0);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    a4[r].init(d);
+                    a4[r].zero();
+                    const int64_t row = row0 + r;
+                    ok4[r] = row < n;
+                    if (ok4[r]) {
+                        const int rs = rowptr[row], re = rowptr[row + 1];
+                        if (skip_long && re - rs > kLongRow) ok4[r] = false;
+                        else
+                            for (int base = rs; base < re; base += 64) {
+                                const int cnt = re - base < 64 ? re - base : 64;
+                                const int32_t c_l = lane < cnt ? col[base + lane] : 0;
+                                const T v_l = lane < cnt ? val[base + lane] : T(0);
+                                gather_accumulate<T, DEPTH>(a4[r], x, d, ldx, 0, cnt,
+                                                            [&](int k) { return __builtin_amdgcn_readlane(c_l, k); },
+                                                            [&](int k) { return wave_get(v_l, k); });
+                            }
+                    }
+                    T s1, s2;
+                    a4[r].sumsq_pair(IsHB<M>::value ? 1 : 0, slope, s1, s2);
+                    if (lane == r) { s_l = s1; sr_l = s2; }
+                }
+                T f_l, t0_l;
+                agg_act_scalars<T>((M*)nullptr, s_l, sr_l, cin, cout, f_l, t0_l);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const T f = wave_get(f_l, r);
+                    a4[r].map([=](T v) { return f * (v > T(0) ? v : (v != v ? v : slope * v)); });
+                    if (IsHB<M>::value) a4[r].set_first(wave_get(t0_l, r));
+                    if (ok4[r]) a4[r].store(out + (row0 + r) * ldo);
+                }
+            }
+            return;
+        }
         for (int64_t row = (int64_t)blockIdx.x * RPB + (threadIdx.x >> 6); row < n; row += (int64_t)gridDim.x * RPB) {
             const int rs = rowptr[row], re = rowptr[row + 1];
             if (skip_long && re - rs > kLongRow) continue;

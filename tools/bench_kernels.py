@@ -97,8 +97,20 @@ def main():
                               ops._p(out), n, d, 1.0, 500.0, 1.0, ops._stream())
             report("p_sample_update(f64 x_t)", sh, n * d * (8 + 4 + 4 + 8) + 4 * n, timeit(upd, a.iters))
             report("moments+standardize(f32)", sh, 3 * B, timeit(lambda: dm.normalization(x), a.iters))
-            # f16x2 operand producers and the HypLinear tail / narrow-input kernels (csrc/gemm_limbs.hip, rowops.hip)
-            if d <= 1535:
+            # the 64-lane-per-row producers / tails below are what the product path runs from 128 (producers) /
+            # 256 (tail) columns on; narrower rows take the generic row kernels measured above (ops.limb_rows_fmt,
+            # manifolds/hyperboloid.py), so they are not timed outside their range
+            if 128 <= d <= 1023:
+                imgb = ops.limb_empty(n, d + 1, dev, "bf16x3")
+                nsl = (d + 1 + 31) // 32 * 32
+
+                def mpackb():
+                    ops._lib.call("hd_mlp_pack_input_bf16x3", ops._p(x64), 1, None, 2, 37.0, ops._p(imgb.buf), n, d, ops._stream())
+                report("mlp_pack_input_bf16x3(f64 x)", sh, n * (8 * d + 6 * nsl), timeit(mpackb, a.iters))
+                dsl = (d + 31) // 32 * 32
+                report("row_pack_bf16x3(hb logmap0)", sh, n * (4 * d + 6 * dsl), timeit(lambda: ops.row_pack(ph, 1, 1.0, "bf16x3"), a.iters))
+                del imgb
+            if 128 <= d <= 1535:
                 img = ops.limb_empty(n, d + 1, dev, "f16x2", zero_amax=False)
                 nsl = (d + 1 + 31) // 32 * 32
 
@@ -108,7 +120,7 @@ def main():
                 report("mlp_pack_input_f16x2(f64 x)", sh, n * (8 * d + 4 * nsl + 8), timeit(mpack, a.iters))
                 dsl = (d + 31) // 32 * 32
                 report("row_pack_f16x2(hb logmap0)", sh, n * (4 * d + 4 * dsl + 8), timeit(lambda: ops.row_pack(ph, 1, 1.0), a.iters))
-            if d <= 512 and d % 4 == 0:
+            if 128 <= d <= 512 and d % 16 == 0:
                 tl = torch.empty_like(x)
 
                 def tail():
@@ -120,7 +132,13 @@ def main():
                 def smallk():
                     ops._lib.call("hd_hb_linear_smallk_f32", ops._p(xin), ops._p(wt), ops._p(tl), n, 24, d, ops.curv(1.0), 3,
                                   ops._stream())
-                report("hb_linear_smallk(24 -> d, flags=3)", sh, n * 4 * (24 + d) + 4 * 24 * d, timeit(smallk, a.iters))
+                report("hb_linear_smallk fp32-fma (24 -> d, flags=3)", sh, n * 4 * (24 + d) + 4 * 24 * d, timeit(smallk, a.iters))
+                wimg = ops.smallk_image_cached(wt.t().contiguous())
+
+                def smallk_mfma():
+                    ops._lib.call("hd_hb_linear_smallk_bf16x3_f32", ops._p(xin), ops._p(wimg), ops._p(tl), n, 24, d, ops.curv(1.0), 3,
+                                  ops._stream())
+                report("hb_linear_smallk bf16x3-mfma (24 -> d, flags=3)", sh, n * 4 * (24 + d) + 4 * 24 * d, timeit(smallk_mfma, a.iters))
                 del tl, xin
             del x, p, q, ph, x64, nz, x0, out
             torch.cuda.empty_cache()
