@@ -329,6 +329,37 @@ __device__ __forceinline__ void agg_act_scalars(HB<T>*, T s, T sr, const Curv& c
     t0 = hd_sqrt(clamp_min((T)cout.K + ns * ns, (T)Lim<T>::hb_eps));       // proj
     f = fe * f1 * f2;
 }
+// hyp_act_homog's chain on scalars: s1 = |x|^2, s2 = |act(x)|^2 (spatial part on the hyperboloid, x0 its time
+// coordinate): HypAct(x) = f * act(x), time coordinate t0
+template <typename T>
+__device__ __forceinline__ void hyp_act_scalars(PB<T>*, T s1, T s2, T, const Curv& cin, const Curv& cout, T& f, T& t0) {
+    const T sci = (T)cin.sc, sco = (T)cout.sc;
+    const T n1 = clamp_min(hd_sqrt(s1), (T)kMinNorm);
+    const T f1 = fast_div((T)(1.0 / cin.sc) * artanh_ref(sci * n1), n1);
+    const T m = f1 * fast_sqrt(s2);
+    const T n2 = clamp_min(m, (T)kMinNorm);
+    const T f2 = fast_div(tanh15(sco * n2), sco * n2);
+    const T n3 = clamp_min(f2 * m, (T)kMinNorm);
+    const T maxnorm = (T)((1.0 - Lim<T>::pb_eps) / cout.sc);
+    const T f3 = n3 > maxnorm ? fast_div(maxnorm, n3) : T(1);
+    f = f1 * f2 * f3;
+    t0 = T(0);
+}
+template <typename T>
+__device__ __forceinline__ void hyp_act_scalars(HB<T>*, T s1, T s2, T x0, const Curv& cin, const Curv& cout, T& f, T& t0) {
+    const T sKi = (T)cin.sK, sKo = (T)cout.sK;
+    const T n1 = clamp_min(hd_sqrt(s1), (T)kMinNorm);
+    const T theta = clamp_min(x0 / sKi, (T)(1.0 + Lim<T>::hb_eps));
+    const T f1 = fast_div(sKi * arcosh_ref(theta), n1);
+    const T m = f1 * fast_sqrt(s2);
+    const T n2 = clamp_min(m, (T)kMinNorm);
+    T shv, chv;
+    sinhcosh15(n2 * (T)(1.0 / cout.sK), shv, chv);
+    const T f2 = fast_div(sKo * shv, n2);
+    const T ns = f2 * m;
+    t0 = hd_sqrt(clamp_min((T)cout.K + ns * ns, (T)Lim<T>::hb_eps));
+    f = f1 * f2;
+}
 template <typename T> struct IsHB { static constexpr bool value = false; };
 template <typename T> struct IsHB<HB<T>> { static constexpr bool value = true; };
 

@@ -21,6 +21,7 @@
 // costs one write of (N,d) and no intermediate (N,d) passes.
 #pragma once
 #include "hd_rowkernels.cuh"
+#include <stdlib.h>
 #include "../../include/hypdiff.h"
 
 namespace hd {
@@ -102,7 +103,8 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 ? 4 : 1)) void spmm_rows(co
         // wavefronts of a block run their rows independently (the barrier pair cost the short rows of the graph-set
         // workloads more than the gather itself)
         const int lane = threadIdx.x & 63;
-        if (sizeof(T) == 4 && epi == E_AGG_ACT && (act == ACT_IDENTITY || act == ACT_RELU || act == ACT_LEAKY_RELU)) {
+        if (sizeof(T) == 4 && epi == E_AGG_ACT && (skip_long & 2) &&
+            (act == ACT_IDENTITY || act == ACT_RELU || act == ACT_LEAKY_RELU)) {
             // fused aggregate + HypAct, four rows per wavefront: the tail's scalar chain (sinh / cosh / arcosh or
             // tanh / artanh, ~150 quarter-rate issues) is wavefront-uniform in the one-row form, i.e. computed 64
             // times over; here lane r evaluates it for row r from the two row sums and hands the factor back
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 ? 4 : 1)) void spmm_rows(co
                     ok4[r] = row < n;
                     if (ok4[r]) {
                         const int rs = rowptr[row], re = rowptr[row + 1];
-                        if (skip_long && re - rs > kLongRow) ok4[r] = false;
+                        if ((skip_long & 1) && re - rs > kLongRow) ok4[r] = false;
                         else
                             for (int base = rs; base < re; base += 64) {
                                 const int cnt = re - base < 64 ? re - base : 64;
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 ? 4 : 1)) void spmm_rows(co
         }
         for (int64_t row = (int64_t)blockIdx.x * RPB + (threadIdx.x >> 6); row < n; row += (int64_t)gridDim.x * RPB) {
             const int rs = rowptr[row], re = rowptr[row + 1];
-            if (skip_long && re - rs > kLongRow) continue;
+            if ((skip_long & 1) && re - rs > kLongRow) continue;
             acc.zero();
             for (int base = rs; base < re; base += 64) {
                 const int cnt = re - base < 64 ? re - base : 64;
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 ? 4 : 1)) void spmm_rows(co
         bool valid = row < n;
         int rs = 0, re = 0;
         if (valid) { rs = rowptr[row]; re = rowptr[row + 1]; }
-        if (skip_long && re - rs > kLongRow) { valid = false; re = rs; }
+        if ((skip_long & 1) && re - rs > kLongRow) { valid = false; re = rs; }
         const int seg0 = rowptr[r0], seg1 = rowptr[r1];
         acc.zero();
         if (seg1 - seg0 <= kStage) {
@@ -253,18 +255,24 @@ int launch_spmm(const char* name, const int32_t* rowptr, const int32_t* col, con
     const int ch = (int)((d + (int64_t)c.g * c.vec - 1) / ((int64_t)c.g * c.vec));
     const int need = ch * c.vec;                       // registers the row needs per lane
     hipStream_t s = (hipStream_t)st;
+    // bit 0: rows longer than kLongRow go to spmm_long; bit 1: four rows per wavefront with the fused analytic tail
+    static const int rows4 = [] { const char* e = getenv("HD_SPMM_ROWS4"); return e ? atoi(e) : 1; }();
+    // (on the hyperboloid the four-row form measured slower on hub-heavy graphs -- 2.79 -> 3.29 ms on the power-law
+    // graph at 10^6 x 256, cause not found; faster on the graph sets: 31 -> 26 us -- so there it is taken only for
+    // adjacencies without long rows; on the ball it won on both, 2.72 -> 2.69 ms and 29.5 -> 20.5 us)
+    const int row_flags = (n_long > 0 ? 1 : 0) | ((rows4 && (!IsHB<M>::value || n_long == 0)) ? 2 : 0);
     int rc = dispatch_cfg<T>(c, [&](auto g, auto v) {
         constexpr int G = decltype(g)::value, V = decltype(v)::value;
         constexpr int R0 = V < 4 ? 4 : V;              // smallest specialisation
         if (sizeof(T) == 4 && need <= R0)
             spmm_rows<M, T, G, V, R0><<<grid_for_rows(n, G), kBlock, 0, s>>>(
-                rowptr, col, (const T*)val, (const T*)x, (T*)out, n, (int)d, ldx, ldo, epi, cin, cout, act, n_long > 0);
+                rowptr, col, (const T*)val, (const T*)x, (T*)out, n, (int)d, ldx, ldo, epi, cin, cout, act, row_flags);
         else if (sizeof(T) == 4 && need <= 8)
             spmm_rows<M, T, G, V, 8><<<grid_for_rows(n, G), kBlock, 0, s>>>(
-                rowptr, col, (const T*)val, (const T*)x, (T*)out, n, (int)d, ldx, ldo, epi, cin, cout, act, n_long > 0);
+                rowptr, col, (const T*)val, (const T*)x, (T*)out, n, (int)d, ldx, ldo, epi, cin, cout, act, row_flags);
         else
             spmm_rows<M, T, G, V, kRegs><<<grid_for_rows(n, G), kBlock, 0, s>>>(
-                rowptr, col, (const T*)val, (const T*)x, (T*)out, n, (int)d, ldx, ldo, epi, cin, cout, act, n_long > 0);
+                rowptr, col, (const T*)val, (const T*)x, (T*)out, n, (int)d, ldx, ldo, epi, cin, cout, act, row_flags);
         return check_launch(name);
     });
     if (rc || n_long == 0) return rc;

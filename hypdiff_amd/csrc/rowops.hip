@@ -104,9 +104,58 @@ HD_MAP1(hd_hb_expmap0, HB, M_EXPMAP0, S_HB_EXPMAP0)
 HD_MAP1(hd_hb_logmap0, HB, M_LOGMAP0, S_HB_LOGMAP0)
 HD_MAP1(hd_hb_expmap0_proj, HB, M_EXPMAP0_PROJ, S_HB_EXPMAP0)
 
+__device__ __forceinline__ float lane_get(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+// HypAct for fp32 rows of 256..512 columns and a positively homogeneous activation: four rows per wavefront, the
+// scalar chain (artanh / tanh or arcosh / sinh / cosh) evaluated once per wavefront, row r in lane r (the generic
+// row kernel evaluates it wavefront-uniformly, i.e. 64 times over: 0.46-0.54 of the HBM peak in round 1)
+template <class M>
+__global__ __launch_bounds__(256) void hyp_act_rows4(const float* __restrict__ in, float* __restrict__ out, int64_t n,
+                                                     int d, Curv cin, Curv cout, float slope) {
+    constexpr int R = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    using TL = Tile<float, 64, 4, 8>;
+    for (int64_t base = ((int64_t)blockIdx.x * 4 + wave) * R; base < n; base += (int64_t)gridDim.x * 4 * R) {
+        TL r[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            r[i].init(d);
+            r[i].load(in + (base + i < n ? base + i : n - 1) * d);
+        }
+        float s1_l = 0.f, s2_l = 0.f, x0_l = 0.f;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            float s1, s2;
+            r[i].sumsq_pair(IsHB<M>::value ? 1 : 0, slope, s1, s2);
+            const float x0 = lane_get(r[i].v[0], 0);
+            if (lane == i) { s1_l = s1; s2_l = s2; x0_l = x0; }
+        }
+        float f_l, t0_l;
+        hyp_act_scalars<float>((M*)nullptr, s1_l, s2_l, x0_l, cin, cout, f_l, t0_l);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const float f = lane_get(f_l, i);
+            r[i].map([=](float v) { return f * (v > 0.f ? v : (v != v ? v : slope * v)); });
+            if (IsHB<M>::value) r[i].set_first(lane_get(t0_l, i));
+            if (base + i < n) r[i].store(out + (base + i) * d);
+        }
+    }
+}
+
 #define HD_ACT(fn, M)                                                                                  \
     extern "C" int fn##_f32(const void* in, void* out, int64_t n, int64_t d, hd_curv ci, hd_curv co,  \
                             int act, void* st) {                                                       \
+        if (n > 0 && d >= 256 && d <= 512 && d % 4 == 0 && in && out && is_aligned16(in) && is_aligned16(out) && \
+            (act == ACT_IDENTITY || act == ACT_RELU || act == ACT_LEAKY_RELU)) {                       \
+            int64_t blocks = (n + 15) / 16;                                                            \
+            blocks = blocks < 8192 ? blocks : 8192;                                                    \
+            hyp_act_rows4<M<float>><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)st>>>(        \
+                (const float*)in, (float*)out, n, (int)d, mk(ci), mk(co),                              \
+                act == ACT_IDENTITY ? 1.f : (act == ACT_RELU ? 0.f : 0.01f));                          \
+            return check_launch(#fn "_f32");                                                           \
+        }                                                                                              \
         return launch_map1<float>(#fn "_f32", (const float*)in, (float*)out, n, d,                    \
                                   OpAct<M<float>, float>{mk(ci), mk(co), act}, (hipStream_t)st);      \
     }                                                                                                  \
@@ -229,10 +278,6 @@ __device__ __forceinline__ void hb_linear_tail_scalars(float s2, int flags, cons
         f = f1 * (sK * arcosh_ref(th) / n2);
         t0 = 0.f;
     }
-}
-
-__device__ __forceinline__ float lane_get(float v, int l) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
 // The per-row scalar chains (logmap0's arcosh, the tail's sinh / cosh / arcosh: ~50 quarter-rate
