@@ -184,8 +184,10 @@ __global__ __launch_bounds__(256) void limb_pack(const float* __restrict__ in, i
 //   PACK_HB_LOG0 Hyperboloid.logmap0(x)               manifolds/hyperboloid.py:103-113 (operand of :122)
 //   PACK_NORM    x itself; also writes |x|_2 per row  manifolds/poincare.py:94-96
 enum PackMode { PACK_MLP = 0, PACK_HB_LOG0 = 1, PACK_NORM = 2 };
-constexpr int kPackChunks = 3;                                    // chunks per lane: cols <= 1536
-template <int MODE, typename TX, bool F16 = true>
+constexpr int kPackChunks = 3;                                    // chunks per lane at most: cols <= 1536
+// NQ = chunks of 8 columns per lane = ceil(columns / 512): rows of <= 512 columns keep 32 row registers per lane
+// instead of 96 (the three-chunk form ran at two workgroups' worth of registers for every width)
+template <int MODE, typename TX, bool F16, int NQ>
 __global__ __launch_bounds__(256) void row_pack_f16x2(const TX* __restrict__ x, const void* __restrict__ t, int t_kind,
                                                       float t_scalar, int rows, int dim, int nslab, Curv cv,
                                                       uint4* __restrict__ out, int* __restrict__ ex,
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256) void row_pack_f16x2(const TX* __restrict__ x, 
     constexpr int RW = 4;
     constexpr int V = 16 / sizeof(TX);
     using VT = typename VecOf<TX>::type;
-    float v[RW][kPackChunks][8];
+    float v[RW][NQ][8];
     float ss_l = 0.f, x0_l = 0.f;
 #pragma unroll
     for (int it = 0; it < RW; ++it) {
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256) void row_pack_f16x2(const TX* __restrict__ x, 
         if constexpr (MODE == PACK_MLP)
             tv = t_kind == 0 ? (float)((const int64_t*)t)[row] : (t_kind == 1 ? ((const float*)t)[row] : t_scalar);
 #pragma unroll
-        for (int q = 0; q < kPackChunks; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int c0 = (lane + 64 * q) * 8;
             if (c0 + 8 <= dim && vec_ok) {
 #pragma unroll
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256) void row_pack_f16x2(const TX* __restrict__ x, 
         if constexpr (MODE != PACK_MLP) {
             float ss = 0.f;
 #pragma unroll
-            for (int q = 0; q < kPackChunks; ++q)
+            for (int q = 0; q < NQ; ++q)
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     if (!(MODE == PACK_HB_LOG0 && q == 0 && e == 0 && lane == 0)) ss += v[it][q][e] * v[it][q][e];
@@ -262,14 +264,14 @@ __global__ __launch_bounds__(256) void row_pack_f16x2(const TX* __restrict__ x, 
         if constexpr (MODE == PACK_HB_LOG0) {
             const float f = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f_l), it));
 #pragma unroll
-            for (int q = 0; q < kPackChunks; ++q)
+            for (int q = 0; q < NQ; ++q)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[it][q][e] *= f;
             if (lane == 0) v[it][0][0] = 0.f;
         }
         float m = 0.f;
 #pragma unroll
-        for (int q = 0; q < kPackChunks; ++q)
+        for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[it][q][e]));
 #pragma unroll
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(256) void row_pack_f16x2(const TX* __restrict__ x, 
             }
         }
 #pragma unroll
-        for (int q = 0; q < kPackChunks; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int ch = lane + 64 * q;
             if (ch >= nchunk) continue;
             if constexpr (F16) {
@@ -804,6 +806,24 @@ template <typename K> static int allow_lds(K kernel, size_t bytes, const char* w
     return HD_OK;
 }
 
+template <int MODE, typename TX, bool F16>
+static int launch_row_pack(const char* who, const TX* x, const void* t, int t_kind, float ts, int64_t rows, int64_t dim,
+                           int64_t cols, Curv cv, void* out, void* ex, void* amax, void* norms, void* st) {
+    const int nslab = (int)((cols + 31) / 32);
+    const dim3 grid((unsigned)((rows + 15) / 16));
+    const size_t lds = (size_t)kLimbs<F16> * nslab * 4 * 17 * sizeof(uint4);
+    auto go = [&](auto nq_c) -> int {
+        constexpr int NQ = decltype(nq_c)::value;
+        if (int rc = allow_lds(row_pack_f16x2<MODE, TX, F16, NQ>, lds, who)) return rc;
+        row_pack_f16x2<MODE, TX, F16, NQ><<<grid, 256, lds, (hipStream_t)st>>>(
+            x, t, t_kind, ts, (int)rows, (int)dim, nslab, cv, (uint4*)out, (int*)ex, (unsigned*)amax, (float*)norms);
+        return check_launch(who);
+    };
+    const int nq = (int)((cols + 511) / 512);
+    return nq <= 1 ? go(std::integral_constant<int, 1>{}) : (nq == 2 ? go(std::integral_constant<int, 2>{})
+                                                                    : go(std::integral_constant<int, 3>{}));
+}
+
 extern "C" int hd_mlp_pack_input_f16x2(const void* x, int x_dtype, const void* t, int t_kind, double t_scalar,
                                        void* out, void* ex, void* amax, int64_t rows, int64_t dim, void* st) {
     HD_REQUIRE(rows >= 0 && dim >= 1 && dim + 1 <= 64 * 8 * kPackChunks, "hd_mlp_pack_input_f16x2: dim out of range (<= %d)",
@@ -812,20 +832,11 @@ extern "C" int hd_mlp_pack_input_f16x2(const void* x, int x_dtype, const void* t
     HD_REQUIRE(x && out && ex && amax && (t || t_kind == 2) && t_kind >= 0 && t_kind <= 2 && is_aligned16(out),
                "hd_mlp_pack_input_f16x2: bad argument");
     HD_REQUIRE(rows < (1LL << 31), "hd_mlp_pack_input_f16x2: size exceeds int32");
-    const int nslab = (int)((dim + 1 + 31) / 32);
-    const dim3 grid((unsigned)((rows + 15) / 16));
-    const size_t lds = (size_t)2 * nslab * 4 * 17 * sizeof(uint4);
-    if (int rc = x_dtype ? allow_lds(row_pack_f16x2<PACK_MLP, double>, lds, "hd_mlp_pack_input_f16x2")
-                         : allow_lds(row_pack_f16x2<PACK_MLP, float>, lds, "hd_mlp_pack_input_f16x2")) return rc;
     if (x_dtype)
-        row_pack_f16x2<PACK_MLP, double><<<grid, 256, lds, (hipStream_t)st>>>(
-            (const double*)x, t, t_kind, (float)t_scalar, (int)rows, (int)dim, nslab, Curv{}, (uint4*)out, (int*)ex,
-            (unsigned*)amax, nullptr);
-    else
-        row_pack_f16x2<PACK_MLP, float><<<grid, 256, lds, (hipStream_t)st>>>(
-            (const float*)x, t, t_kind, (float)t_scalar, (int)rows, (int)dim, nslab, Curv{}, (uint4*)out, (int*)ex,
-            (unsigned*)amax, nullptr);
-    return check_launch("hd_mlp_pack_input_f16x2");
+        return launch_row_pack<PACK_MLP, double, true>("hd_mlp_pack_input_f16x2", (const double*)x, t, t_kind, (float)t_scalar,
+                                                       rows, dim, dim + 1, Curv{}, out, ex, amax, nullptr, st);
+    return launch_row_pack<PACK_MLP, float, true>("hd_mlp_pack_input_f16x2", (const float*)x, t, t_kind, (float)t_scalar, rows,
+                                                  dim, dim + 1, Curv{}, out, ex, amax, nullptr, st);
 }
 
 extern "C" int hd_row_pack_f16x2_f32(const void* x, int mode, hd_curv c, void* out, void* ex, void* amax, void* norms,
@@ -837,20 +848,12 @@ extern "C" int hd_row_pack_f16x2_f32(const void* x, int mode, hd_curv c, void* o
     HD_REQUIRE(x && out && ex && amax && is_aligned16(out) && (mode != PACK_NORM || norms),
                "hd_row_pack_f16x2_f32: null or misaligned pointer");
     HD_REQUIRE(rows < (1LL << 31), "hd_row_pack_f16x2_f32: size exceeds int32");
-    const int nslab = (int)((dim + 31) / 32);
-    const dim3 grid((unsigned)((rows + 15) / 16));
-    const size_t lds = (size_t)2 * nslab * 4 * 17 * sizeof(uint4);
     const Curv cv{c.c, c.sqrt_c, c.K, c.sqrt_K};
-    if (int rc = mode == PACK_HB_LOG0 ? allow_lds(row_pack_f16x2<PACK_HB_LOG0, float>, lds, "hd_row_pack_f16x2_f32")
-                                      : allow_lds(row_pack_f16x2<PACK_NORM, float>, lds, "hd_row_pack_f16x2_f32")) return rc;
     if (mode == PACK_HB_LOG0)
-        row_pack_f16x2<PACK_HB_LOG0, float><<<grid, 256, lds, (hipStream_t)st>>>(
-            (const float*)x, nullptr, 2, 0.f, (int)rows, (int)dim, nslab, cv, (uint4*)out, (int*)ex, (unsigned*)amax, nullptr);
-    else
-        row_pack_f16x2<PACK_NORM, float><<<grid, 256, lds, (hipStream_t)st>>>(
-            (const float*)x, nullptr, 2, 0.f, (int)rows, (int)dim, nslab, cv, (uint4*)out, (int*)ex, (unsigned*)amax,
-            (float*)norms);
-    return check_launch("hd_row_pack_f16x2_f32");
+        return launch_row_pack<PACK_HB_LOG0, float, true>("hd_row_pack_f16x2_f32", (const float*)x, nullptr, 2, 0.f, rows, dim,
+                                                          dim, cv, out, ex, amax, nullptr, st);
+    return launch_row_pack<PACK_NORM, float, true>("hd_row_pack_f16x2_f32", (const float*)x, nullptr, 2, 0.f, rows, dim, dim, cv,
+                                                   out, ex, amax, norms, st);
 }
 
 // the same one-pass producers for the bf16x3 format (three limbs, no row exponents): 48 B of LDS per element
@@ -864,20 +867,11 @@ extern "C" int hd_mlp_pack_input_bf16x3(const void* x, int x_dtype, const void* 
     HD_REQUIRE(x && out && (t || t_kind == 2) && t_kind >= 0 && t_kind <= 2 && is_aligned16(out),
                "hd_mlp_pack_input_bf16x3: bad argument");
     HD_REQUIRE(rows < (1LL << 31), "hd_mlp_pack_input_bf16x3: size exceeds int32");
-    const int nslab = (int)((dim + 1 + 31) / 32);
-    const dim3 grid((unsigned)((rows + 15) / 16));
-    const size_t lds = (size_t)3 * nslab * 4 * 17 * sizeof(uint4);
-    if (int rc = x_dtype ? allow_lds(row_pack_f16x2<PACK_MLP, double, false>, lds, "hd_mlp_pack_input_bf16x3")
-                         : allow_lds(row_pack_f16x2<PACK_MLP, float, false>, lds, "hd_mlp_pack_input_bf16x3")) return rc;
     if (x_dtype)
-        row_pack_f16x2<PACK_MLP, double, false><<<grid, 256, lds, (hipStream_t)st>>>(
-            (const double*)x, t, t_kind, (float)t_scalar, (int)rows, (int)dim, nslab, Curv{}, (uint4*)out, nullptr,
-            nullptr, nullptr);
-    else
-        row_pack_f16x2<PACK_MLP, float, false><<<grid, 256, lds, (hipStream_t)st>>>(
-            (const float*)x, t, t_kind, (float)t_scalar, (int)rows, (int)dim, nslab, Curv{}, (uint4*)out, nullptr,
-            nullptr, nullptr);
-    return check_launch("hd_mlp_pack_input_bf16x3");
+        return launch_row_pack<PACK_MLP, double, false>("hd_mlp_pack_input_bf16x3", (const double*)x, t, t_kind, (float)t_scalar,
+                                                        rows, dim, dim + 1, Curv{}, out, nullptr, nullptr, nullptr, st);
+    return launch_row_pack<PACK_MLP, float, false>("hd_mlp_pack_input_bf16x3", (const float*)x, t, t_kind, (float)t_scalar, rows,
+                                                   dim, dim + 1, Curv{}, out, nullptr, nullptr, nullptr, st);
 }
 
 extern "C" int hd_row_pack_bf16x3_f32(const void* x, int mode, hd_curv c, void* out, void* norms, int64_t rows,
@@ -888,19 +882,12 @@ extern "C" int hd_row_pack_bf16x3_f32(const void* x, int mode, hd_curv c, void* 
     if (rows == 0) return HD_OK;
     HD_REQUIRE(x && out && is_aligned16(out) && (mode != PACK_NORM || norms), "hd_row_pack_bf16x3_f32: null or misaligned pointer");
     HD_REQUIRE(rows < (1LL << 31), "hd_row_pack_bf16x3_f32: size exceeds int32");
-    const int nslab = (int)((dim + 31) / 32);
-    const dim3 grid((unsigned)((rows + 15) / 16));
-    const size_t lds = (size_t)3 * nslab * 4 * 17 * sizeof(uint4);
     const Curv cv{c.c, c.sqrt_c, c.K, c.sqrt_K};
-    if (int rc = mode == PACK_HB_LOG0 ? allow_lds(row_pack_f16x2<PACK_HB_LOG0, float, false>, lds, "hd_row_pack_bf16x3_f32")
-                                      : allow_lds(row_pack_f16x2<PACK_NORM, float, false>, lds, "hd_row_pack_bf16x3_f32")) return rc;
     if (mode == PACK_HB_LOG0)
-        row_pack_f16x2<PACK_HB_LOG0, float, false><<<grid, 256, lds, (hipStream_t)st>>>(
-            (const float*)x, nullptr, 2, 0.f, (int)rows, (int)dim, nslab, cv, (uint4*)out, nullptr, nullptr, nullptr);
-    else
-        row_pack_f16x2<PACK_NORM, float, false><<<grid, 256, lds, (hipStream_t)st>>>(
-            (const float*)x, nullptr, 2, 0.f, (int)rows, (int)dim, nslab, cv, (uint4*)out, nullptr, nullptr, (float*)norms);
-    return check_launch("hd_row_pack_bf16x3_f32");
+        return launch_row_pack<PACK_HB_LOG0, float, false>("hd_row_pack_bf16x3_f32", (const float*)x, nullptr, 2, 0.f, rows, dim,
+                                                           dim, cv, out, nullptr, nullptr, nullptr, st);
+    return launch_row_pack<PACK_NORM, float, false>("hd_row_pack_bf16x3_f32", (const float*)x, nullptr, 2, 0.f, rows, dim, dim,
+                                                    cv, out, nullptr, nullptr, norms, st);
 }
 
 extern "C" int hd_limb_unpack_f32(const void* in, int64_t rows, int64_t cols, void* out, int64_t ld, void* st) {
