@@ -466,7 +466,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // v_mfma_f32_16x16x32_{bf16,f16} (one k-step per 32-deep slab): same cycles and LDS reads as
 // 32x32x16, but the chip holds a higher clock on this shape under load (measured +13 % on the
 // denoiser chain).
-template <int BNT, int WAVES, bool F16>
+template <int BNT, int WAVES, bool F16, int NBUF = 2>
 __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict__ Ag, const uint4* __restrict__ Wg,
                                                   const float* __restrict__ bias, const float* __restrict__ resid,
                                                   float* __restrict__ C, uint4* __restrict__ CL, int M, int N,
@@ -479,7 +479,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
     constexpr int MT = 4, NT16 = WCOLS / 16;     // 16x16 MFMA tiles per wavefront
     constexpr int QA = 8 * L / WAVES, QW = (4 * L * BNT / 64) / WAVES;   // 1 KiB pieces per wavefront and slab
     constexpr int CH_A = 4 * L * 128, CH_W = 4 * L * BNT, CH_BUF = CH_A + CH_W;
-    __shared__ uint4 lds[2 * CH_BUF];
+    // NBUF = 1: one LDS buffer -- a slab's fragments are in registers before the multiply starts, so the next slab can
+    // stream into the same buffer meanwhile (one slab in flight instead of two; 48 KB for the 128x128 tile, which
+    // then runs two workgroups per CU with 64x64 per wavefront: a third of the LDS traffic per flop of the 128x64 form)
+    __shared__ uint4 lds[NBUF * CH_BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WCN, wc = wave % WCN;
     const int ntiles = tiles_m * tiles_n;
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
     int vt = blockIdx.x, tm, tn, tm2 = 0, tn2 = 0;
     decode(vt, tm, tn);
     // a next tile is prefetched across the tile boundary only when every tile has >= 2 slabs
-    bool has_next = nslab >= 2 && vt + (int)gridDim.x < ntiles;
+    bool has_next = (NBUF == 1 || nslab >= 2) && vt + (int)gridDim.x < ntiles;
     if (has_next) decode(vt + gridDim.x, tm2, tn2);
     const uint4 *a_cur = a_ptr(tm), *w_cur = w_ptr(tn), *a_nxt = a_ptr(tm2), *w_nxt = w_ptr(tn2);
     int pb = 0;                                            // slab t of the current tile lives in buffer (pb + t) & 1
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
         }
     }
     HD_STAGE(a_cur, w_cur, 0, 0)
-    if (nslab > 1) HD_STAGE(a_cur, w_cur, 1, 1)
+    if (NBUF == 2 && nslab > 1) HD_STAGE(a_cur, w_cur, 1, 1)
     for (;;) {
         f32x4 acc[MT][NT16];
 #pragma unroll
@@ -572,11 +575,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
         for (int t = 0; t < nslab; ++t) {
-            if (t + 1 < nslab || has_next) wait_vmcnt<QA + QW>();
+            if (NBUF == 2 && (t + 1 < nslab || has_next)) wait_vmcnt<QA + QW>();
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                       // slab t has landed, for every wave
             uint4 fa[MT][L], fw[NT16][L];
-            const uint4* la = &lds[((pb + t) & 1) * CH_BUF];
+            const uint4* la = &lds[(NBUF == 2 ? ((pb + t) & 1) : 0) * CH_BUF];
 #pragma unroll
             for (int l = 0; l < L; ++l) {
 #pragma unroll
@@ -586,8 +589,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                       // every wave holds its fragments: buffer free
-            if (t + 2 < nslab) HD_STAGE(a_cur, w_cur, t + 2, (pb + t) & 1)
-            else if (has_next) HD_STAGE(a_nxt, w_nxt, t + 2 - nslab, (pb + t) & 1)
+            if constexpr (NBUF == 2) {
+                if (t + 2 < nslab) HD_STAGE(a_cur, w_cur, t + 2, (pb + t) & 1)
+                else if (has_next) HD_STAGE(a_nxt, w_nxt, t + 2 - nslab, (pb + t) & 1)
+            } else {
+                if (t + 1 < nslab) HD_STAGE(a_cur, w_cur, t + 1, 0)
+                else if (has_next) HD_STAGE(a_nxt, w_nxt, 0, 0)
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -732,16 +740,18 @@ int gemm_impl(const char* who, const void* A, const void* W, const void* bias, c
     }
     const int tiles_m = (int)((M + 127) / 128);
     const int nslab = (int)((K + 31) / 32), nslab_out = (int)((N + 31) / 32);
-    // tile: 'N' = 128x64 / 4 wavefronts, 'W' = 128x128 / 4 wavefronts, 'X' = 128x128 / 8 wavefronts.
+    // tile: 'N' = 128x64 / 4 wavefronts, 'W' = 128x128 / 4 wavefronts, 'X' = 128x128 / 8 wavefronts, all with two LDS
+    // buffers; 'T' = 128x64 / 4 wavefronts and 'S' = 128x128 / 4 wavefronts with ONE buffer (a slab's fragments sit in
+    // registers before its multiplies start, so the next slab streams into the same buffer: one slab in flight).
     // Persistent grid: the workgroups that are resident at once (a multiple of 8, so a
     // workgroup's tiles stay on one XCD), unless K fits one slab.
-    // Measured on the denoiser shapes (M = 15 777): bf16x3 'N' (two workgroups per CU), f16x2 'X' (two
-    // workgroups = 16 wavefronts per CU; 64 KiB of LDS each).
+    // Measured on the denoiser shapes (M = 15 777), chain of five GEMMs: bf16x3 'T' 485-497 us, 'S' 499-512 (de-phased),
+    // 'N' 515-530 (round-2 default until then), same boxes; f16x2 'X' (two workgroups = 16 wavefronts per CU).
     // tuning knobs and the CU count are read ONCE per process (HD_GEMM_TUNE_RELOAD=1 re-reads them on every
     // launch: the tile-configuration sweeps of tools/bench_chain.py)
     struct Knobs { char cfg_bf, cfg_f16; int persist, per_cu, n_cu, reload, phase, delay_ns; };
     static Knobs knobs = [] {
-        Knobs k{'N', 'X', 1, 0, 256, 0, 7, 500};
+        Knobs k{'T', 'X', 1, 0, 256, 0, -1, 500};
         if (const char* e = getenv("HD_GEMM_LIMBS_PHASE")) k.phase = atoi(e);
         if (const char* e = getenv("HD_GEMM_LIMBS_DELAY_NS")) k.delay_ns = atoi(e);
         if (const char* e = getenv("HD_GEMM_LIMBS_TUNE")) k.cfg_bf = e[0];
@@ -764,7 +774,11 @@ int gemm_impl(const char* who, const void* A, const void* W, const void* bias, c
     }
     const char cfg = F16 ? knobs.cfg_f16 : knobs.cfg_bf;
     const int n_cu = knobs.n_cu, persist = knobs.persist, per_cu = knobs.per_cu;
-#define HD_LAUNCH(BNT_, WAVES_, PER_CU_)                                                                   \
+    // de-phased start (phase mode 7) unless HD_GEMM_LIMBS_PHASE says otherwise; the single-buffer 128x64 form ('T')
+    // measured better without it on three boxes (chain 485-497 us against 504-523)
+    const int phase = knobs.phase >= 0 ? knobs.phase : (cfg == 'T' ? 0 : 7);
+#define HD_LAUNCH(BNT_, WAVES_, PER_CU_) HD_LAUNCHB(BNT_, WAVES_, PER_CU_, 2)
+#define HD_LAUNCHB(BNT_, WAVES_, PER_CU_, NBUF_)                                                                   \
     {                                                                                                      \
         const int tiles_n = (int)((N + BNT_ - 1) / BNT_);                                                  \
         const int64_t ntiles = (int64_t)tiles_m * tiles_n;                                                 \
@@ -772,14 +786,17 @@ int gemm_impl(const char* who, const void* A, const void* W, const void* bias, c
         int64_t grid = ntiles;                                                                             \
         const int64_t resident = (int64_t)(n_cu * (per_cu > 0 ? per_cu : PER_CU_)) / 8 * 8;                \
         if (persist && nslab >= 2 && resident >= 8 && grid > resident) grid = resident;                    \
-        gemm_limbs<BNT_, WAVES_, F16><<<dim3((unsigned)grid), dim3(WAVES_ * 64), 0, (hipStream_t)st>>>(    \
+        gemm_limbs<BNT_, WAVES_, F16, NBUF_><<<dim3((unsigned)grid), dim3(WAVES_ * 64), 0, (hipStream_t)st>>>( \
             (const uint4*)A, (const uint4*)W, (const float*)bias, (const float*)resid, (float*)C, (uint4*)CL,  \
             (int)M, (int)N, nslab, (int)ldc, epi, tiles_m, tiles_n, nslab_out, sc,                         \
-            grid < ntiles ? knobs.phase : 0, (int)((int64_t)knobs.delay_ns * nslab / 10), (float*)Z);      \
+            grid < ntiles ? phase : 0, (int)((int64_t)knobs.delay_ns * nslab / 10), (float*)Z);            \
     }
     if (cfg == 'W') HD_LAUNCH(128, 4, (F16 ? 2 : 1))
     else if (cfg == 'X') HD_LAUNCH(128, 8, (F16 ? 2 : 1))
+    else if (cfg == 'S') HD_LAUNCHB(128, 4, 2, 1)
+    else if (cfg == 'T') HD_LAUNCHB(64, 4, 2, 1)
     else HD_LAUNCH(64, 4, (F16 ? 3 : 2))
+#undef HD_LAUNCHB
 #undef HD_LAUNCH
     return check_launch(who);
 }
