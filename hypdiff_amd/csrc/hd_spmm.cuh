@@ -260,7 +260,9 @@ int launch_spmm(const char* name, const int32_t* rowptr, const int32_t* col, con
     // (on the hyperboloid the four-row form measured slower on hub-heavy graphs -- 2.79 -> 3.29 ms on the power-law
     // graph at 10^6 x 256, cause not found; faster on the graph sets: 31 -> 26 us -- so there it is taken only for
     // adjacencies without long rows; on the ball it won on both, 2.72 -> 2.69 ms and 29.5 -> 20.5 us)
-    const int row_flags = (n_long > 0 ? 1 : 0) | ((rows4 && (!IsHB<M>::value || n_long == 0)) ? 2 : 0);
+    // (and only when there are rows enough to keep every SIMD busy with four-row tasks: a 2708-row graph ran its
+    // aggregate 45 us in the four-row form against 20 us one row per wavefront -- latency-bound, not chain-bound)
+    const int row_flags = (n_long > 0 ? 1 : 0) | ((rows4 && n >= 8192 && (!IsHB<M>::value || n_long == 0)) ? 2 : 0);
     int rc = dispatch_cfg<T>(c, [&](auto g, auto v) {
         constexpr int G = decltype(g)::value, V = decltype(v)::value;
         constexpr int R0 = V < 4 ? 4 : V;              // smallest specialisation
