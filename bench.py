@@ -6,7 +6,9 @@ One "step" = one pass of the hot path over one batch of synthetic input:
     SynEgo1000-shaped graph set (1197 graphs, sum N = 15 777 rows), followed by one
     direction-diffusion p_sample step (mlp denoiser + fused update, T = 1000 tables)
     over the (sum N, 512) latents.
-value = rows processed by all ranks / wall time (inputs resident in HBM before timing).
+value = rows processed by all ranks / wall time (inputs resident in HBM before timing).  The two phases of a
+step read different inputs, so the encode is issued on a second HIP stream and joined before the step ends
+(`--one-stream`: both on one stream; reported as the `one_stream` secondary otherwise).
 
     python bench.py --gpus N --steps K --warmup W
 For N > 1 launch one rank per GPU (torch.distributed.run); each rank owns its own
@@ -118,8 +120,8 @@ def build_workload(dim, T, seed, device):
 
 def one_step(w, t, ev=None):
     """One step.  The two phases read different inputs (node features + adjacency / current
-    latents); when w["side_stream"] is set (secondary `two_streams` leg) the encode is issued on
-    that stream and joined before the step returns."""
+    latents); when w["side_stream"] is set (the headline arrangement; `--one-stream` turns it off) the encode
+    is issued on that stream and joined before the step returns."""
     side = w.get("side_stream")
     if side is None:
         if ev is not None:
@@ -275,8 +277,11 @@ def main():
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--timesteps", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--one-stream", action="store_true",
+                    help="issue both phases of a step on ONE HIP stream (default: encode on a second stream, joined per "
+                         "step -- the two phases read different inputs)")
     ap.add_argument("--no-overlap-leg", action="store_true",
-                    help="skip the secondary leg that issues encode and p_sample on two HIP streams")
+                    help="skip the secondary leg that repeats the steps with the other stream arrangement")
     ap.add_argument("--no-exact-leg", action="store_true", help="skip the comparison legs on the other fp32 GEMM kernels")
     ap.add_argument("--train-steps", type=int, default=20, help="steps of the secondary training leg (0 = skip)")
     ap.add_argument("--sharded-steps", type=int, default=5, help="steps of the secondary row-sharded leg (0 = skip)")
@@ -308,7 +313,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    elapsed, _, _ = timed_steps(w, T, a.steps, a.warmup, barrier, ops, dist, device)
+    # Headline: the encode of a step is issued on a second HIP stream and joined before the step ends (its HBM-bound
+    # kernels run in the partly empty tile rounds of the denoiser GEMMs: 0.67-0.69 against 0.72-0.74 ms on one stream
+    # since the single-buffer GEMM of round 2; before that it measured no gain).  The per-kernel pass below stays on one
+    # stream: a kernel's duration there is its own, not that of two kernels sharing the chip.
+    side = None if a.one_stream else torch.cuda.Stream()
+    if side is not None:
+        w["side_stream"] = side
+    try:
+        elapsed, _, _ = timed_steps(w, T, a.steps, a.warmup, barrier, ops, dist, device)
+    finally:
+        w.pop("side_stream", None)
     el_inst, events, phase = timed_steps(w, T, a.steps, min(a.warmup, 3), barrier, ops, dist, device, instrument=True)
 
     # dominant kernel: the fp32 GEMM of the denoiser / HypLinear (live HIP-event timing per launch)
@@ -343,15 +358,18 @@ def main():
                                "Hyperboloid c=1 HGCN encode (21->%d->%d) + direction-diffusion p_sample "
                                "(mlp denoiser, T=%d tables)" % (w["n"], w["nnz"], a.dim, a.dim, T),
                    "rows_per_gpu": w["n"], "dim": a.dim, "timesteps": T, "parallelism": "graph-set shards x%d" % world,
-                   "gemm_mode": ops.GEMM_MODE, "streams": "one HIP stream"},
+                   "gemm_mode": ops.GEMM_MODE,
+                   "streams": "one HIP stream" if side is None else
+                              "two HIP streams (encode || p_sample inside a step, joined per step)"},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                      "traffic_unit": "HBM bytes per launch (mean)", "traffic_source": traffic_src,
                      "peak_note": PEAK_NOTES[dom],
                      "achieved_over_f32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS,
                      "timing": "HIP events on the launch stream around every GEMM launch of a second, instrumented "
-                               "pass over the same K steps (%.4f ms per step with the 17 event records per step in "
-                               "the queue; the headline K steps carry none)" % (el_inst / a.steps * 1e3),
+                               "pass over the same K steps, both phases on ONE stream so that a launch's duration is "
+                               "the kernel's own (%.4f ms per step with the 17 event records per step in the queue; "
+                               "the headline K steps carry none)" % (el_inst / a.steps * 1e3),
                      "algorithmic_bytes_per_launch": d["bytes"] / max(1, d["launches"]), "launches": d["launches"],
                      "kernel_ms_per_step": d["ms"] / a.steps, "all_gemm_ms_per_step": gemm_ms / a.steps,
                      "other_gemm_kernels": {k: {"launches": v["launches"], "TFLOP/s": v["flops"] / (v["ms"] * 1e-3) / 1e12,
@@ -374,7 +392,12 @@ def main():
                 if m2 == mode:
                     continue
                 ops.GEMM_MODE = m2
-                el2, _, _ = timed_steps(w, T, a.steps, min(a.warmup, 3), barrier, ops, dist, device)
+                if side is not None:
+                    w["side_stream"] = side              # the same stream arrangement as the headline
+                try:
+                    el2, _, _ = timed_steps(w, T, a.steps, min(a.warmup, 3), barrier, ops, dist, device)
+                finally:
+                    w.pop("side_stream", None)
                 _, ev2, _ = timed_steps(w, T, a.steps, 1, barrier, ops, dist, device, instrument=True)
                 per2 = gemm_summary(ev2)
                 k2 = max(per2, key=lambda k: per2[k]["ms"])
@@ -389,11 +412,14 @@ def main():
     if not a.no_overlap_leg:
         # secondary: the two phases of a step read different inputs, so the encode can be issued on a
         # second HIP stream and its HBM-bound kernels fill the gaps of the MFMA-bound denoiser GEMMs
-        w["side_stream"] = torch.cuda.Stream()
+        if side is None:
+            w["side_stream"] = torch.cuda.Stream()
         try:
             el3, _, _ = timed_steps(w, T, a.steps, min(a.warmup, 3), barrier, ops, dist, device)
-            out["two_streams"] = {"value": rows_total / el3, "unit": "node-steps/s", "ms_per_step": el3 / a.steps * 1e3,
-                                  "note": "same steps with encode and p_sample of a step on two HIP streams, joined per step"}
+            key = "two_streams" if side is None else "one_stream"
+            out[key] = {"value": rows_total / el3, "unit": "node-steps/s", "ms_per_step": el3 / a.steps * 1e3,
+                        "note": "same steps with encode and p_sample of a step on two HIP streams, joined per step"
+                                if side is None else "same steps with both phases on one HIP stream"}
         finally:
             w.pop("side_stream", None)
     if a.train_steps > 0:

@@ -6,6 +6,6 @@ cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_$c
   rm -rf $OUT; mkdir -p $OUT
-  timeout -s KILL 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary "$@" > $OUT/log.txt 2>&1 || { tail -20 $OUT/log.txt; exit 1; }
+  timeout -s KILL 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --one-stream "$@" > $OUT/log.txt 2>&1 || { tail -20 $OUT/log.txt; exit 1; }
 done
 python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_FETCH_SIZE $GRAFT_REPO_ROOT/gpurun_out/pmc_${TAG}_WRITE_SIZE > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_hbm_traffic.json
