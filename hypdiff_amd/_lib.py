@@ -34,6 +34,7 @@ _agg = [P, P, P, P, P, I64, I64, HdCurv, HdCurv, c_int, c_int, P, I64, P]
 SIZE_QUERIES = {
     "hd_moments_workspace_doubles": [],
     "hd_gemm_tn_workspace_floats": [I64, I64, I64],
+    "hd_gemm_tn_bf16x3_workspace_floats": [I64, I64, I64],
     "hd_colsum_workspace_floats": [I64, I64],
     "hd_mse_workspace_doubles": [],
     "hd_hkm_workspace_doubles": [I64, I64, I64],
@@ -99,6 +100,7 @@ SIGNATURES = {
     "hd_limb_unpack_f16x2_f32": [P, P, I64, I64, P, I64, P],
     "hd_gemm_f16x2_f32": [P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, c_int, c_float, c_float, P],
     "hd_gemm_tn_f32": [P, P, P, I64, I64, I64, I64, I64, I64, P, P],
+    "hd_gemm_tn_bf16x3_f32": [P, P, P, P, I64, I64, I64, I64, I64, I64, P, P],
     "hd_transpose_f32": [P, P, I64, I64, I64, I64, P],
     "hd_colsum_f32": [P, P, I64, I64, I64, P, P],
     "hd_bias_gelu_f32": [P, P, P, P, I64, I64, c_int, P],

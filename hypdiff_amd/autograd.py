@@ -53,33 +53,54 @@ def gemm_ex(a, w, bias, resid, aux, c, c2, epi):
                    "gemm_f32_mfma" if ops.GEMM_MODE == "exact" else "gemm_f32_bf16x3"))
 
 
-def gemm_tn(a, b, out=None):
-    """out[P,Q] = a[R,P]^T @ b[R,Q] (weight gradient)."""
+def gemm_tn(a, b, out=None, colsum_out=None, want_colsum=False):
+    """out[P,Q] = a[R,P]^T @ b[R,Q] (weight gradient).  With `colsum_out` / `want_colsum` the bias gradient
+    colsum(a) comes back as well (one launch on the limb kernel, hd_colsum_f32 otherwise): returns (out, colsum)."""
+    if colsum_out is not None or want_colsum:
+        return _gemm_tn_cs(a, b, out, colsum_out)
+    return _gemm_tn_cs(a, b, out, None, False)[0]
+
+
+def _gemm_tn_cs(a, b, out, cs, want_cs=True):
     R, P = a.shape
     Q = b.shape[1]
     if P % 4 or Q % 4 or a.stride(0) % 4 or b.stride(0) % 4 or a.data_ptr() % 16 or b.data_ptr() % 16:
         # odd widths (e.g. the D = 14 latents of config 1): zero-padded copies, result sliced back
         res = gemm_tn(ops._pad_k(a, (P + 3) // 4 * 4), ops._pad_k(b, (Q + 3) // 4 * 4))[:P, :Q]
         if out is None:
-            return res.contiguous()
-        out.copy_(res)
-        return out
+            out = res.contiguous()
+        else:
+            out.copy_(res)
+        return out, (colsum(a, out=cs) if want_cs else None)
     if out is not None and (out.data_ptr() % 16 or not out.is_contiguous()):
-        out.copy_(gemm_tn(a, b))                  # the kernel stores 16-byte rows
-        return out
+        res, cs = _gemm_tn_cs(a, b, None, cs, want_cs)        # the kernel stores 16-byte rows
+        out.copy_(res)
+        return out, cs
     if out is None:
         out = torch.empty(P, Q, dtype=torch.float32, device=a.device)
-    ws = _ws(_lib.load().hd_gemm_tn_workspace_floats(R, P, Q), torch.float32, a.device)
+    # fp32-faithful limb arithmetic on the bf16 matrix cores unless GEMM_MODE asks for the exact fp32 MFMA
+    limbs = ops.GEMM_MODE != "exact" and out.stride(0) % 4 == 0
+    sym = "hd_gemm_tn_bf16x3" if limbs else "hd_gemm_tn"
+    ws = _ws(getattr(_lib.load(), sym + "_workspace_floats")(R, P, Q), torch.float32, a.device)
+    fused = limbs and want_cs and (cs is None or (cs.data_ptr() % 16 == 0 and cs.is_contiguous()))
+    if fused and cs is None:
+        cs = torch.empty(P, dtype=torch.float32, device=a.device)
     ev = ops.GEMM_EVENTS
     if ev is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.call("hd_gemm_tn_f32", ops._p(a), ops._p(b), ops._p(out), R, P, Q, a.stride(0), b.stride(0), out.stride(0),
-              ops._p(ws), ops._stream())
+    if limbs:
+        _lib.call(sym + "_f32", ops._p(a), ops._p(b), ops._p(out), ops._p(cs) if fused else None, R, P, Q, a.stride(0),
+                  b.stride(0), out.stride(0), ops._p(ws), ops._stream())
+    else:
+        _lib.call(sym + "_f32", ops._p(a), ops._p(b), ops._p(out), R, P, Q, a.stride(0), b.stride(0), out.stride(0),
+                  ops._p(ws), ops._stream())
     if ev is not None:
         e1.record()
         ev.append((e0, e1, 2.0 * R * P * Q, 4.0 * (R * P + R * Q + P * Q)))
-    return out
+    if want_cs and not fused:
+        cs = colsum(a, out=cs)
+    return out, cs
 
 
 def transpose(w):
@@ -212,16 +233,14 @@ class LinearStack(torch.autograd.Function):
             bv = sink.view_for(bp) if sink is not None else None
             if wv is not None and bv is not None:
                 if shp[1] == x_l.shape[1]:
-                    gemm_tn(dz, x_l, out=wv)
+                    gemm_tn(dz, x_l, out=wv, colsum_out=bv)
                 else:                                       # zero-padded first layer: slice the pad columns off
-                    wv.copy_(gemm_tn(dz, x_l)[:, :shp[1]])
-                colsum(dz, out=bv)
+                    wv.copy_(gemm_tn(dz, x_l, colsum_out=bv)[0][:, :shp[1]])
                 sink.delivered(bp)
                 sink.delivered(wp)
             else:
-                dw = gemm_tn(dz, x_l)
+                dw, grads[2 * l + 1] = gemm_tn(dz, x_l, want_colsum=True)
                 grads[2 * l] = dw if tuple(dw.shape) == shp else dw[:, :shp[1]].contiguous()
-                grads[2 * l + 1] = colsum(dz)
             if l == 0 and not ctx.need_x:
                 break
             if ctx.limbs:

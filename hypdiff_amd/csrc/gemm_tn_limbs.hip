@@ -1,0 +1,206 @@
+// Weight gradient dW = dz^T @ x on the bf16 matrix cores, fp32-faithful (3 bf16 limbs per operand element, 6 exact
+// limb products per fp32 product, as the limb GEMM of gemm_limbs.hip).  Autograd of diff.py:113-118 /
+// diff_graphset.py:64-75 over models/direction_diffusion.py:56-69, ddpm.py:9-41; the reference has no kernel of its
+// own here.  C[P][Q] = sum_r A[r][p] B[r][q]: the contraction index r is the ROW index of both operands, while a lane
+// of v_mfma_f32_16x16x32_bf16 supplies 8 consecutive k of one row.  The transpose costs nothing extra: a thread
+// loads the same 4 columns of 8 consecutive rows (8 float4 loads; a wavefront's loads are 512-byte runs of A and of
+// B), so it holds 8 consecutive r for each of its 4 columns in registers, splits them into limbs and writes the 12
+// operand chunks of 16 bytes straight in fragment order ([limb][kq][column], the slab layout of the limb images).
+// 128x128 tile, 4 wavefronts of 64x64, ONE LDS buffer of 48 KB (a slab's 24 fragments are in registers before its
+// multiplies start; the next slab's rows are already in flight into registers), two workgroups per CU.  The rows are
+// cut into slices (one workgroup per tile and slice, partial tiles summed in slice order by a second kernel:
+// bit-reproducible, no atomics), as in hd_gemm_tn_f32, which stays the exact-fp32 form.  The bias gradient
+// db[p] = sum_r A[r][p] rides along: the workgroups of the first tile column add up the fp32 rows they stage anyway
+// (registers, then the four wavefronts in order, then the slices in order), which replaces hd_colsum_f32's two launches.
+#include "hd_common.cuh"
+#include "hd_limbs.cuh"
+#include "../../include/hypdiff.h"
+
+using namespace hd;
+
+namespace {
+
+constexpr int TP = 128, TQ = 128, TR = 32;
+
+inline int host_slices(int64_t R, int64_t tiles) {
+    // ~768 workgroups in flight (two per CU and a tail), slices of at least 8 slabs
+    int64_t s = (768 + tiles - 1) / tiles;
+    const int64_t max_s = (R + 8 * TR - 1) / (8 * TR);
+    s = s < 1 ? 1 : (s > max_s ? max_s : s);
+    return (int)(s > 64 ? 64 : s);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_bf16x3(const float* __restrict__ A, const float* __restrict__ B,
+                                                      float* __restrict__ out, int R, int P, int Q, int lda, int ldb,
+                                                      int ldo, int chunk, int tiles_q, int tiles, size_t slice_stride,
+                                                      float* __restrict__ cs_out) {
+    __shared__ uint4 lds[2 * 3 * 4 * 128];                       // [operand][limb][kq][column]: 48 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x % tiles, slice = blockIdx.x / tiles;
+    const int tp = tile / tiles_q, tq = tile - tp * tiles_q;
+    const int p0 = tp * TP, q0 = tq * TQ;
+    const int r_begin = slice * chunk, r_end = r_begin + chunk < R ? r_begin + chunk : R;
+    const int nslab = (r_end - r_begin + TR - 1) / TR;
+    // staging role of this thread: rows 8 kq .. 8 kq + 7 of the slab (kq = wave), 4 columns of A (lanes 0..31) or of B
+    const int kq_s = wave, half = lane >> 5, c4 = (lane & 31) * 4;
+    const float* src = half ? B : A;
+    const int ld = half ? ldb : lda;
+    const int col = (half ? q0 : p0) + c4;
+    const bool col_ok = col < (half ? Q : P);                    // P, Q multiples of 4: a quad is inside or outside
+    float4 pre[8];
+    const bool do_cs = cs_out != nullptr && tq == 0;             // uniform over the workgroup
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_slab = [&](int t) {
+        const int rb = r_begin + t * TR + kq_s * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int r = rb + e;
+            pre[e] = (col_ok && r < r_end) ? *reinterpret_cast<const float4*>(src + (size_t)r * ld + col)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_slab = [&]() {
+        uint4* base = lds + half * (3 * 4 * 128) + kq_s * 128 + c4;
+        if (do_cs) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { cs.x += pre[e].x; cs.y += pre[e].y; cs.z += pre[e].z; cs.w += pre[e].w; }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = c == 0 ? pre[e].x : (c == 1 ? pre[e].y : (c == 2 ? pre[e].z : pre[e].w));
+            uint4 h, m, l;
+            limb_split8(v, h, m, l);
+            base[c] = h;
+            base[4 * 128 + c] = m;
+            base[8 * 128 + c] = l;
+        }
+    };
+    // operand maps of v_mfma_f32_16x16x32: lane (r16, kq) supplies column r16 of its 16-column block, k = 8 kq .. + 7
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int a_off = kq * 128 + wr * 64 + r16, b_off = 3 * 4 * 128 + kq * 128 + wc * 64 + r16;
+    lf32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = lf32x4{0.f, 0.f, 0.f, 0.f};
+    if (nslab > 0) load_slab(0);
+    for (int t = 0; t < nslab; ++t) {
+        store_slab();
+        __syncthreads();                                          // the slab is in LDS
+        uint4 fa[4][3], fb[4][3];
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i][l] = lds[a_off + l * 4 * 128 + i * 16];
+                fb[i][l] = lds[b_off + l * 4 * 128 + i * 16];
+            }
+        __syncthreads();                                          // every wavefront holds its fragments: buffer free
+        if (t + 1 < nslab) load_slab(t + 1);                      // in flight during the multiplies
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lf32x4 c = acc[i][j];
+                // first operand = B columns (q), second = A columns (p): D column = lane & 15 = p, D rows 4 kq + reg = q
+#define HD_MM(bl, al) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(lbf16x8, fb[j][bl]), \
+                                                          __builtin_bit_cast(lbf16x8, fa[i][al]), c, 0, 0, 0);
+                HD_MM(0, 2) HD_MM(2, 0) HD_MM(1, 1) HD_MM(0, 1) HD_MM(1, 0) HD_MM(0, 0)
+#undef HD_MM
+                acc[i][j] = c;
+            }
+    }
+    if (do_cs) {                                                  // the last slab's fragments are out of LDS (barrier above)
+        float* red = reinterpret_cast<float*>(lds);
+        if (half == 0) *reinterpret_cast<float4*>(red + wave * 128 + c4) = cs;
+        __syncthreads();
+        if (tid < 128 && p0 + tid < P)
+            cs_out[(size_t)slice * P + p0 + tid] = ((red[tid] + red[128 + tid]) + red[256 + tid]) + red[384 + tid];
+    }
+    float* o = out + (size_t)slice * slice_stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = p0 + wr * 64 + i * 16 + r16;
+        if (p >= P) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = q0 + wc * 64 + j * 16 + 4 * kq;
+            if (q < Q)                                            // Q % 4 == 0: the quad is inside or outside
+                *reinterpret_cast<float4*>(o + (size_t)p * ldo + q) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    }
+}
+
+// out[i] = sum over slices, in slice order; the column sums (count2 of them per slice, 0 = none) follow the tiles
+__global__ __launch_bounds__(256) void tn_reduce(const float* __restrict__ ws, int nsl, size_t count, float* __restrict__ out,
+                                                 const float* __restrict__ ws2, size_t count2, float* __restrict__ out2) {
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < count + count2; i += (size_t)gridDim.x * 256 * 4) {
+        const bool second = i >= count;
+        const float* src = second ? ws2 + (i - count) : ws + i;
+        const size_t stride = second ? count2 : count;
+        float4 s = *reinterpret_cast<const float4*>(src);
+        for (int k = 1; k < nsl; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)k * stride);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(second ? out2 + (i - count) : out + i) = s;
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t hd_gemm_tn_bf16x3_workspace_floats(int64_t R, int64_t P, int64_t Q) {
+    if (R < 1 || P < 1 || Q < 1) return 0;
+    const int64_t tiles = ((P + TP - 1) / TP) * ((Q + TQ - 1) / TQ);
+    const int s = host_slices(R, tiles);
+    return s > 1 ? (int64_t)s * (P * Q + P) : 0;                  // tiles, then column sums, per slice
+}
+
+extern "C" int hd_gemm_tn_bf16x3_f32(const void* A, const void* B, void* C, void* colsum_a, int64_t R, int64_t P, int64_t Q,
+                                     int64_t lda, int64_t ldb, int64_t ldc, void* workspace, void* st) {
+    HD_REQUIRE(R >= 0 && P >= 1 && Q >= 1, "hd_gemm_tn_bf16x3_f32: bad shape R=%lld P=%lld Q=%lld", (long long)R,
+               (long long)P, (long long)Q);
+    HD_REQUIRE(A && B && C, "hd_gemm_tn_bf16x3_f32: null pointer");
+    HD_REQUIRE(R < (1LL << 31) && P < (1LL << 31) && Q < (1LL << 31), "hd_gemm_tn_bf16x3_f32: size exceeds int32");
+    HD_REQUIRE(P % 4 == 0 && Q % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && is_aligned16(A) &&
+                   is_aligned16(B) && is_aligned16(C),
+               "hd_gemm_tn_bf16x3_f32: P, Q and the leading dimensions must be multiples of 4 and A, B, C 16-byte aligned");
+    HD_REQUIRE(lda >= P && ldb >= Q && ldc >= Q, "hd_gemm_tn_bf16x3_f32: leading dimension too small");
+    HD_REQUIRE(!colsum_a || is_aligned16(colsum_a), "hd_gemm_tn_bf16x3_f32: colsum_a must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)st;
+    if (R == 0) {
+        HD_REQUIRE(ldc == Q, "hd_gemm_tn_bf16x3_f32: empty reduction needs a contiguous output");
+        if (hipMemsetAsync(C, 0, (size_t)P * Q * sizeof(float), s) != hipSuccess ||
+            (colsum_a && hipMemsetAsync(colsum_a, 0, (size_t)P * sizeof(float), s) != hipSuccess))
+            return check_launch("hd_gemm_tn_bf16x3_f32");
+        return HD_OK;
+    }
+    const int tiles_p = (int)((P + TP - 1) / TP), tiles_q = (int)((Q + TQ - 1) / TQ);
+    const int tiles = tiles_p * tiles_q;
+    const int splits = host_slices(R, tiles);
+    int chunk = (int)((R + splits - 1) / splits);
+    chunk = (chunk + TR - 1) / TR * TR;
+    const int nsl = (int)((R + chunk - 1) / chunk);
+    HD_REQUIRE((int64_t)tiles * nsl < (1LL << 31), "hd_gemm_tn_bf16x3_f32: too many workgroups");
+    if (nsl > 1) {
+        HD_REQUIRE(workspace && is_aligned16(workspace), "hd_gemm_tn_bf16x3_f32: workspace of hd_gemm_tn_bf16x3_workspace_floats() floats required");
+        HD_REQUIRE(ldc == Q, "hd_gemm_tn_bf16x3_f32: split reduction needs a contiguous output (ldc == Q)");
+        const size_t count = (size_t)P * Q;
+        float* cs_ws = colsum_a ? (float*)workspace + (size_t)nsl * count : nullptr;
+        gemm_tn_bf16x3<<<dim3((unsigned)(tiles * nsl)), 256, 0, s>>>((const float*)A, (const float*)B, (float*)workspace,
+                                                                       (int)R, (int)P, (int)Q, (int)lda, (int)ldb, (int)Q,
+                                                                       chunk, tiles_q, tiles, (size_t)P * Q, cs_ws);
+        const size_t count2 = colsum_a ? (size_t)P : 0;
+        int blocks = (int)(((count + count2) / 4 + 255) / 256);
+        blocks = blocks < 2048 ? blocks : 2048;
+        tn_reduce<<<blocks, 256, 0, s>>>((const float*)workspace, nsl, count, (float*)C, cs_ws, count2, (float*)colsum_a);
+    } else {
+        gemm_tn_bf16x3<<<dim3((unsigned)tiles), 256, 0, s>>>((const float*)A, (const float*)B, (float*)C, (int)R, (int)P,
+                                                               (int)Q, (int)lda, (int)ldb, (int)ldc, chunk, tiles_q, tiles, 0,
+                                                               (float*)colsum_a);
+    }
+    return check_launch("hd_gemm_tn_bf16x3_f32");
+}

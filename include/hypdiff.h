@@ -340,6 +340,14 @@ int hd_gemm_f16x2_f32(const void* A, const void* ea, const void* amax_a, const v
 int64_t hd_gemm_tn_workspace_floats(int64_t R, int64_t P, int64_t Q);
 int hd_gemm_tn_f32(const void* A, const void* B, void* C, int64_t R, int64_t P, int64_t Q, int64_t lda, int64_t ldb,
                    int64_t ldc, void* workspace, void* stream);
+/* The same weight gradient on the bf16 matrix cores (3 bf16 limbs per operand element split in registers on the way
+ * into LDS, 6 limb products per fp32 product: fp32-faithful as hd_gemm_limbs_f32); same arguments, C also 16-byte
+ * aligned with ldc a multiple of 4; workspace of hd_gemm_tn_bf16x3_workspace_floats floats.  colsum_a (P floats, 16-byte
+ * aligned, or NULL) also receives the bias gradient db[p] = sum_r A[r][p] in fp32, summed in a fixed order from the rows
+ * the kernel stages anyway (in place of hd_colsum_f32). */
+int64_t hd_gemm_tn_bf16x3_workspace_floats(int64_t R, int64_t P, int64_t Q);
+int hd_gemm_tn_bf16x3_f32(const void* A, const void* B, void* C, void* colsum_a, int64_t R, int64_t P, int64_t Q,
+                          int64_t lda, int64_t ldb, int64_t ldc, void* workspace, void* stream);
 /* out[cols, rows] = in[rows, cols]^T */
 int hd_transpose_f32(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out,
                      void* stream);

@@ -369,22 +369,30 @@ def test_hip_gcndec_vs_oracle():
 
 # ------------------------------------------------------------------ training GEMM forms, raw
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["bf16x3", "exact"])
 @pytest.mark.parametrize("R,P,Q", [(1, 4, 4), (31, 8, 132), (64, 128, 128), (257, 900, 516), (1000, 14, 17),
-                                   (5000, 260, 68), (15777, 64, 512)])
-def test_hip_gemm_tn_shapes(R, P, Q):
+                                   (5000, 260, 68), (15777, 64, 512), (15777, 800, 900)])
+def test_hip_gemm_tn_shapes(R, P, Q, mode, monkeypatch):
     """dW = A^T B over ragged slice / tile boundaries, exact on small-integer data (fp32 sums of
-    integers below 2^24 are exact in any order) and within fp32 reassociation on Gaussian data."""
-    from hypdiff_amd import autograd as hag
+    integers below 2^24 are exact in any order) and within fp32 reassociation on Gaussian data; both forms
+    (hd_gemm_tn_bf16x3_f32: 3 bf16 limbs on the matrix cores, hd_gemm_tn_f32: fp32 MFMA)."""
+    from hypdiff_amd import autograd as hag, ops
+    monkeypatch.setattr(ops, "GEMM_MODE", mode)
     rs = np.random.RandomState(R + P + Q)
     a = rs.randint(-3, 4, size=(R, P)).astype(np.float32)
     b = rs.randint(-3, 4, size=(R, Q)).astype(np.float32)
-    got = hag.gemm_tn(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    got, cs = hag.gemm_tn(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), want_colsum=True)
     assert np.array_equal(got.cpu().numpy(), (a.astype(np.float64).T @ b.astype(np.float64)).astype(np.float32))
+    assert np.array_equal(cs.cpu().numpy(), a.sum(0, dtype=np.float64).astype(np.float32))     # the bias gradient
     a, b = rs.standard_normal((R, P)).astype(np.float32), rs.standard_normal((R, Q)).astype(np.float32)
-    got = hag.gemm_tn(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    cs = torch.full((P,), float("nan"), device="cuda")
+    got = torch.full((P, Q), float("nan"), device="cuda")
+    hag.gemm_tn(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), out=got, colsum_out=cs)
     want = a.astype(np.float64).T @ b.astype(np.float64)
     bound = 2e-6 * (np.abs(a).astype(np.float64).T @ np.abs(b).astype(np.float64))
     assert (np.abs(got.cpu().numpy() - want) <= bound + 1e-30).all()
+    assert (np.abs(cs.cpu().numpy() - a.sum(0, dtype=np.float64)) <= 2e-6 * np.abs(a).sum(0, dtype=np.float64)).all()
+    assert torch.equal(hag.gemm_tn(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()), got)     # reproducible
 
 
 @pytest.mark.gpu
