@@ -12,6 +12,7 @@
 // bit-reproducible, no atomics), as in hd_gemm_tn_f32, which stays the exact-fp32 form.  The bias gradient
 // db[p] = sum_r A[r][p] rides along: the workgroups of the first tile column add up the fp32 rows they stage anyway
 // (registers, then the four wavefronts in order, then the slices in order), which replaces hd_colsum_f32's two launches.
+#include <stdlib.h>
 #include "hd_common.cuh"
 #include "hd_limbs.cuh"
 #include "../../include/hypdiff.h"
@@ -22,9 +23,14 @@ namespace {
 
 constexpr int TP = 128, TQ = 128, TR = 32;
 
+inline int tn_target_wgs() {
+    static const int v = [] { const char* e = getenv("HD_TN_WGS"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 512; }();
+    return v;
+}
+
 inline int host_slices(int64_t R, int64_t tiles) {
-    // ~768 workgroups in flight (two per CU and a tail), slices of at least 8 slabs
-    int64_t s = (768 + tiles - 1) / tiles;
+    // one resident round: 256 CUs x 2 workgroups (212 VGPRs, 48 KB LDS); slices of at least 8 slabs
+    int64_t s = tn_target_wgs() / tiles;
     const int64_t max_s = (R + 8 * TR - 1) / (8 * TR);
     s = s < 1 ? 1 : (s > max_s ? max_s : s);
     return (int)(s > 64 ? 64 : s);
@@ -32,11 +38,16 @@ inline int host_slices(int64_t R, int64_t tiles) {
 
 __global__ __launch_bounds__(256) void gemm_tn_bf16x3(const float* __restrict__ A, const float* __restrict__ B,
                                                       float* __restrict__ out, int R, int P, int Q, int lda, int ldb,
-                                                      int ldo, int chunk, int tiles_q, int tiles, size_t slice_stride,
+                                                      int ldo, int chunk, int tiles_q, int tiles, int total, size_t slice_stride,
                                                       float* __restrict__ cs_out) {
     __shared__ uint4 lds[2 * 3 * 4 * 128];                       // [operand][limb][kq][column]: 48 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.x % tiles, slice = blockIdx.x / tiles;
+    // workgroup b runs on XCD b % 8: give each XCD a contiguous run of (slice, tile) pairs, so that the tiles that share
+    // a slice's rows of A and B meet in one L2
+    const int per_xcd = (gridDim.x + 7) >> 3;
+    const int vid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (vid >= total) return;                                     // uniform: the grid is rounded up to a multiple of 8
+    const int tile = vid % tiles, slice = vid / tiles;
     const int tp = tile / tiles_q, tq = tile - tp * tiles_q;
     const int p0 = tp * TP, q0 = tq * TQ;
     const int r_begin = slice * chunk, r_end = r_begin + chunk < R ? r_begin + chunk : R;
@@ -190,17 +201,18 @@ extern "C" int hd_gemm_tn_bf16x3_f32(const void* A, const void* B, void* C, void
         HD_REQUIRE(ldc == Q, "hd_gemm_tn_bf16x3_f32: split reduction needs a contiguous output (ldc == Q)");
         const size_t count = (size_t)P * Q;
         float* cs_ws = colsum_a ? (float*)workspace + (size_t)nsl * count : nullptr;
-        gemm_tn_bf16x3<<<dim3((unsigned)(tiles * nsl)), 256, 0, s>>>((const float*)A, (const float*)B, (float*)workspace,
-                                                                       (int)R, (int)P, (int)Q, (int)lda, (int)ldb, (int)Q,
-                                                                       chunk, tiles_q, tiles, (size_t)P * Q, cs_ws);
+        gemm_tn_bf16x3<<<dim3((unsigned)((tiles * nsl + 7) / 8 * 8)), 256, 0, s>>>(
+            (const float*)A, (const float*)B, (float*)workspace, (int)R, (int)P, (int)Q, (int)lda, (int)ldb, (int)Q, chunk,
+            tiles_q, tiles, tiles * nsl, (size_t)P * Q, cs_ws);
         const size_t count2 = colsum_a ? (size_t)P : 0;
         int blocks = (int)(((count + count2) / 4 + 255) / 256);
         blocks = blocks < 2048 ? blocks : 2048;
         tn_reduce<<<blocks, 256, 0, s>>>((const float*)workspace, nsl, count, (float*)C, cs_ws, count2, (float*)colsum_a);
     } else {
-        gemm_tn_bf16x3<<<dim3((unsigned)tiles), 256, 0, s>>>((const float*)A, (const float*)B, (float*)C, (int)R, (int)P,
-                                                               (int)Q, (int)lda, (int)ldb, (int)ldc, chunk, tiles_q, tiles, 0,
-                                                               (float*)colsum_a);
+        gemm_tn_bf16x3<<<dim3((unsigned)((tiles + 7) / 8 * 8)), 256, 0, s>>>((const float*)A, (const float*)B, (float*)C, (int)R,
+                                                                               (int)P, (int)Q, (int)lda, (int)ldb, (int)ldc,
+                                                                               chunk, tiles_q, tiles, tiles, 0,
+                                                                               (float*)colsum_a);
     }
     return check_launch("hd_gemm_tn_bf16x3_f32");
 }
