@@ -22,6 +22,12 @@ class HdChainLayer(ctypes.Structure):
                 ("add_emb", c_int32)]
 
 
+class HdPackJob(ctypes.Structure):
+    """struct hd_pack_job of include/hypdiff.h"""
+    _fields_ = [("src", c_void_p), ("image", c_void_p), ("ld", c_int64), ("rows", c_int64), ("cols", c_int64),
+                ("transposed", c_int32)]
+
+
 P = c_void_p
 I64 = c_int64
 _map1 = [P, P, I64, I64, HdCurv, P]
@@ -89,6 +95,7 @@ SIGNATURES = {
     "hd_gemm_f32_ex": [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, c_int, P],
     "hd_gemm_f32_bf16x3": [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, c_int, P],
     "hd_limb_pack_f32": [P, I64, I64, I64, P, P],
+    "hd_limb_pack_multi_f32": [POINTER(HdPackJob), c_int, P],
     "hd_limb_unpack_f32": [P, I64, I64, P, I64, P],
     "hd_gemm_limbs_f32": [P, P, P, P, P, P, I64, I64, I64, I64, c_int, P],
     "hd_gemm_limbs_train_f32": [P, P, P, P, P, P, P, I64, I64, I64, I64, c_int, P],

@@ -167,11 +167,18 @@ class LinearStack(torch.autograd.Function):
             # operands travel as bf16x3 limb images (split once per element by the producing GEMM's write-out);
             # fp32 copies are written where the backward pass reads them: z (gelu') and x_l (weight gradient)
             xs, zs = [x], []
-            a = ops.limb_pack(x[:, : ws_[0].shape[1]], "bf16x3")
+            # the input, every W_l and (for the input gradients of the backward pass) every W_l^T above the first
+            # layer become limb images in ONE launch: the weights change every step, so nothing can be cached
+            L = len(kinds)
+            train = any(w.requires_grad for w in ws_)
+            imgs = ops.limb_pack_multi([(x[:, : ws_[0].shape[1]], False)] + [(w.detach(), False) for w in ws_] +
+                                       ([(w.detach(), True) for w in ws_[1:]] if train else []))
+            a, wimgs = imgs[0], imgs[1:1 + L]
+            ctx.wt_imgs = [None] + imgs[1 + L:] if train else None
             h = x
             for l, kind in enumerate(kinds):
                 last = l == len(kinds) - 1
-                wl, _ = ops.weight_limbs(ws_[l], "bf16x3")
+                wl = wimgs[l]
                 z, h, a = gemm_limbs_train(a, wl, bs_[l].detach(), None, 1 if kind == GELU else 0, want_z=kind == GELU,
                                            want_limbs=not last)
                 zs.append(z)
@@ -248,7 +255,7 @@ class LinearStack(torch.autograd.Function):
                 # by this launch's write-out), W_l^T split once per step
                 if l == top:
                     dz_img = ops.limb_pack(dz, "bf16x3")
-                wt_img = ops.limb_pack(transpose(w), "bf16x3")
+                wt_img = ctx.wt_imgs[l] if ctx.wt_imgs is not None else ops.limb_pack_multi([(w, True)])[0]
                 _, dz, dz_img = gemm_limbs_train(dz_img, wt_img, None, zs[l - 1], 3, want_limbs=l - 1 >= 1)
                 continue
             wt = transpose(w)                                    # (K_l, N_l): contraction over N_l

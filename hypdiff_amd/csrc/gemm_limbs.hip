@@ -176,6 +176,56 @@ __global__ __launch_bounds__(256) void limb_pack(const float* __restrict__ in, i
     }
 }
 
+// Several bf16x3 images in ONE launch (the weights of a training step: W_l for the forward pass and W_l^T for the
+// input gradient, 9 small matrices for the mlp denoiser, each a launch of a few microseconds otherwise).  A job's
+// logical matrix is src or src^T; threads of a wavefront take consecutive logical rows, so the transposed read is
+// contiguous across lanes and the plain one is 32 bytes per lane.
+constexpr int kMaxPackJobs = 16;
+struct PackJob { const float* src; uint4* out; int64_t ld; int rows, cols, nslab, trans; unsigned block0; };
+struct PackJobs { int n; PackJob j[kMaxPackJobs]; };
+
+__global__ __launch_bounds__(256) void limb_pack_multi(const PackJobs jobs) {
+    int k = 0;
+    while (k + 1 < jobs.n && blockIdx.x >= jobs.j[k + 1].block0) ++k;
+    const PackJob& J = jobs.j[k];
+    const int64_t id = (int64_t)(blockIdx.x - J.block0) * 256 + threadIdx.x;   // ((rb * nslab + s) * 4 + kc) * 128 + r
+    const int r = (int)(id & 127);
+    const int64_t q = id >> 7;
+    const int kc = (int)(q & 3);
+    const int64_t tile = q >> 2;
+    const int s = (int)(tile % J.nslab);
+    const int64_t rb = tile / J.nslab;
+    const int64_t row = rb * 128 + r;
+    const int c0 = s * 32 + kc * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (row < J.rows) {
+        if (J.trans) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (c0 + e < J.cols) v[e] = J.src[(int64_t)(c0 + e) * J.ld + row];
+        } else {
+            const float* p = J.src + row * J.ld + c0;
+            if (c0 + 8 <= J.cols && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+                const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (c0 + e < J.cols) v[e] = p[e];
+            }
+        }
+    }
+    uint4* o = J.out + tile * kTileOf<false> + kc * 128 + r;
+    uint2 h0, m0, l0, h1, m1, l1;
+    split4(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
+    split4(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);
+    o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    o[4 * 128] = make_uint4(m0.x, m0.y, m1.x, m1.y);
+    o[8 * 128] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+
 // Row producers that write the f16x2 image of a GEMM operand directly, in one pass over the rows: a
 // wavefront takes a row at a time, a lane owns the 8-column chunks lane, lane + 64, ...; the row maximum (and the
 // row norm, where the map needs one) is a wavefront reduction, so the row is read once and no fp32
@@ -808,6 +858,35 @@ extern "C" int64_t hd_limb_image_bytes_f16x2(int64_t rows, int64_t cols) { retur
 
 extern "C" int hd_limb_pack_f32(const void* in, int64_t ld, int64_t rows, int64_t cols, void* out, void* st) {
     return pack_impl<false>("hd_limb_pack_f32", in, ld, rows, cols, out, nullptr, nullptr, st);
+}
+extern "C" int hd_limb_pack_multi_f32(const hd_pack_job* jobs, int n_jobs, void* st) {
+    HD_REQUIRE(n_jobs >= 0 && n_jobs <= kMaxPackJobs && (jobs || n_jobs == 0),
+               "hd_limb_pack_multi_f32: between 0 and %d jobs per call", kMaxPackJobs);
+    PackJobs pj;
+    pj.n = 0;
+    uint64_t blocks = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const hd_pack_job& j = jobs[i];
+        HD_REQUIRE(j.rows >= 0 && j.cols >= 1 && j.ld >= j.cols, "hd_limb_pack_multi_f32: job %d: bad shape", i);
+        if (j.rows == 0) continue;
+        HD_REQUIRE(j.src && j.image && is_aligned16(j.image), "hd_limb_pack_multi_f32: job %d: null or misaligned pointer", i);
+        HD_REQUIRE(j.rows < (1LL << 31) && j.cols < (1LL << 31), "hd_limb_pack_multi_f32: job %d: size exceeds int32", i);
+        const int64_t lrows = j.transposed ? j.cols : j.rows, lcols = j.transposed ? j.rows : j.cols;
+        PackJob& o = pj.j[pj.n++];
+        o.src = (const float*)j.src;
+        o.out = (uint4*)j.image;
+        o.ld = j.ld;
+        o.rows = (int)lrows;
+        o.cols = (int)lcols;
+        o.nslab = (int)((lcols + 31) / 32);
+        o.trans = j.transposed ? 1 : 0;
+        o.block0 = (unsigned)blocks;
+        blocks += (uint64_t)((lrows + 127) / 128) * o.nslab * 2;           // 512 chunks per tile and slab = 2 blocks
+        HD_REQUIRE(blocks < (1ULL << 31), "hd_limb_pack_multi_f32: too many workgroups");
+    }
+    if (pj.n == 0) return HD_OK;
+    limb_pack_multi<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)st>>>(pj);
+    return check_launch("hd_limb_pack_multi_f32");
 }
 extern "C" int hd_limb_pack_f16x2_f32(const void* in, int64_t ld, int64_t rows, int64_t cols, void* out, void* ex,
                                       void* amax, void* st) {

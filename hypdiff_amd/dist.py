@@ -145,6 +145,8 @@ class GradBucket:
             if c[0] <= lo < c[1] and p.grad is not None and p.grad.data_ptr() != self.flat[lo:hi].data_ptr():
                 self.flat[lo:hi].view_as(p).copy_(p.grad)
                 p.grad = self.flat[lo:hi].view_as(p)
+        if not _collective(self._group):      # one process: the bucket is only the sink of the backward kernels
+            return
         view.div_(dist.get_world_size(self._group))
         self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self._group, async_op=True))
 
@@ -195,7 +197,7 @@ class DataParallelTrainer:
         """loss_fn() -> scalar loss of this rank's shard.  Returns the (local) loss tensor."""
         self.bucket.zero_()
         loss = loss_fn()
-        if self.overlap and _collective(self.group):
+        if self.overlap:
             from . import autograd as hag
             self.bucket.arm(self.group)
             hag.GRAD_SINK = self.bucket           # the stack's backward writes dW / db straight into the bucket

@@ -324,6 +324,23 @@ def limb_pack(x, fmt="bf16x3"):
     return img
 
 
+def limb_pack_multi(items):
+    """[(fp32 matrix, transposed), ...] -> [LimbImage, ...] (bf16x3) in one launch per 16 matrices: the image of the
+    matrix itself or of its transpose (hd_limb_pack_multi_f32)."""
+    imgs, jobs = [], []
+    for x, tr in items:
+        _dev(x)
+        assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1
+        rows, cols = (x.shape[1], x.shape[0]) if tr else (x.shape[0], x.shape[1])
+        img = limb_empty(rows, cols, x.device, "bf16x3")
+        imgs.append(img)
+        jobs.append(_lib.HdPackJob(x.data_ptr(), img.buf.data_ptr(), x.stride(0), x.shape[0], x.shape[1], 1 if tr else 0))
+    for i in range(0, len(jobs), 16):
+        part = jobs[i:i + 16]
+        _lib.call("hd_limb_pack_multi_f32", (_lib.HdPackJob * len(part))(*part), len(part), _stream())
+    return imgs
+
+
 def limb_unpack(img):
     out = torch.empty(img.rows, img.cols, dtype=torch.float32, device=img.buf.device)
     if img.fmt == "bf16x3":

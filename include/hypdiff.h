@@ -267,6 +267,17 @@ int hd_gemm_limbs_train_f32(const void* A, const void* W, const void* bias, cons
                             int64_t M, int64_t N, int64_t K, int64_t ldc, int epi, void* stream);
 int64_t hd_limb_image_bytes(int64_t rows, int64_t cols);
 int hd_limb_pack_f32(const void* in, int64_t ld, int64_t rows, int64_t cols, void* out, void* stream);
+/* Several bf16x3 images in one launch (at most 16 jobs): job i packs src (rows x cols fp32, row stride ld) or, with
+ * `transposed`, src^T (the cols x rows matrix W^T that the input gradient dz @ W contracts with; autograd of F.linear,
+ * models/direction_diffusion.py:56-69 -- replaces hd_transpose_f32 + hd_limb_pack_f32) into `image`
+ * (hd_limb_image_bytes of the packed matrix's shape). */
+typedef struct hd_pack_job {
+    const void* src;
+    void* image;
+    int64_t ld, rows, cols;
+    int32_t transposed;
+} hd_pack_job;
+int hd_limb_pack_multi_f32(const hd_pack_job* jobs, int n_jobs, void* stream);
 int hd_limb_unpack_f32(const void* in, int64_t rows, int64_t cols, void* out, int64_t ld, void* stream);
 /* A stack of nn.Linear layers on a small batch (rows <= 512, widths <= 512) in ONE cooperative launch: MLP.forward /
  * Backbone.forward of ddpm.py:9-41 (config 3: 24 layers of width 512 at B = 200).  Layer i: y = x W_i^T + bias_i, then

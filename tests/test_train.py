@@ -396,6 +396,24 @@ def test_hip_gemm_tn_shapes(R, P, Q, mode, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_hip_limb_pack_multi_matches_single():
+    """hd_limb_pack_multi_f32 (all weight images of a training step in one launch, W and W^T) writes the same bytes
+    as hd_limb_pack_f32 of the matrix / of hd_transpose_f32's output; 17 jobs = two launches; ragged shapes."""
+    from hypdiff_amd import autograd as hag, ops
+    rs = np.random.RandomState(5)
+    shapes = [(800, 513), (900, 800), (1, 1), (129, 33), (512, 700), (7, 260)] * 3
+    mats = [torch.from_numpy((rs.standard_normal(sh) * 10.0 ** rs.randint(-3, 4)).astype(np.float32)).cuda()
+            for sh in shapes[:17]]
+    mats[4] = torch.from_numpy(rs.standard_normal((512, 704)).astype(np.float32)).cuda()[:, :700]     # row stride 704
+    items = [(m, i % 2 == 1) for i, m in enumerate(mats)]
+    got = ops.limb_pack_multi(items)
+    for (m, tr), img in zip(items, got):
+        want = ops.limb_pack(hag.transpose(m) if tr else m, "bf16x3")
+        assert (img.rows, img.cols) == (want.rows, want.cols)
+        assert torch.equal(img.buf, want.buf), (tuple(m.shape), tr)
+
+
+@pytest.mark.gpu
 def test_hip_dgrad_epilogue_transpose_colsum():
     from hypdiff_amd import autograd as hag
     rs = np.random.RandomState(2)
