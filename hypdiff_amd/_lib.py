@@ -28,6 +28,11 @@ class HdPackJob(ctypes.Structure):
                 ("transposed", c_int32)]
 
 
+class HdAdamJob(ctypes.Structure):
+    """struct hd_adam_job of include/hypdiff.h"""
+    _fields_ = [("param", c_void_p), ("offset", c_int64), ("count", c_int64)]
+
+
 P = c_void_p
 I64 = c_int64
 _map1 = [P, P, I64, I64, HdCurv, P]
@@ -109,6 +114,7 @@ SIGNATURES = {
     "hd_gemm_tn_f32": [P, P, P, I64, I64, I64, I64, I64, I64, P, P],
     "hd_gemm_tn_bf16x3_f32": [P, P, P, P, I64, I64, I64, I64, I64, I64, P, P],
     "hd_transpose_f32": [P, P, I64, I64, I64, I64, P],
+    "hd_adam_step_f32": [POINTER(HdAdamJob), c_int, P, P, P, c_double, c_double, c_double, c_double, I64, P],
     "hd_colsum_f32": [P, P, I64, I64, I64, P, P],
     "hd_bias_gelu_f32": [P, P, P, P, I64, I64, c_int, P],
     "hd_gelu_bwd_f32": [P, P, P, I64, P],

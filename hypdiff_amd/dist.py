@@ -169,6 +169,36 @@ class GradBucket:
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
+class BucketAdam:
+    """torch.optim.Adam with its defaults (no weight decay, no amsgrad: diff.py:107, diff_graphset.py:66) over a
+    GradBucket of fp32 CUDA parameters, as ONE launch per step (hd_adam_step_f32) instead of torch's seven
+    multi-tensor launches.  State = two flat arrays laid out like the bucket.  Every parameter of the bucket is updated
+    on every step: one that received no gradient sees g = 0 (torch would skip it; the denoisers have no such
+    parameter).  Results agree with torch's to rounding (same operation order, fused-multiply-add contraction aside)."""
+
+    def __init__(self, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        from . import _lib
+        assert all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in bucket.params)
+        self.bucket, self.lr, self.betas, self.eps, self.t = bucket, float(lr), tuple(betas), float(eps), 0
+        self.exp_avg = torch.zeros_like(bucket.flat)
+        self.exp_avg_sq = torch.zeros_like(bucket.flat)
+        self._lib = _lib
+
+    def step(self):
+        from . import ops
+        lib, b = self._lib, self.bucket
+        self.t += 1
+        ops._dev(b.flat)
+        jobs = [lib.HdAdamJob(p.data_ptr(), b.offsets[id(p)][0], p.numel()) for p in b.params]
+        for i in range(0, len(jobs), 32):
+            part = jobs[i:i + 32]
+            lib.call("hd_adam_step_f32", (lib.HdAdamJob * len(part))(*part), len(part), ops._p(b.flat), ops._p(self.exp_avg),
+                     ops._p(self.exp_avg_sq), self.lr, self.betas[0], self.betas[1], self.eps, self.t, ops._stream())
+        # the kernel wrote the parameters behind autograd's back: bump their versions, which key the caches of
+        # limb images and padded / transposed weight copies
+        torch.autograd.graph.increment_version(b.params)
+
+
 class DataParallelTrainer:
     """Data-parallel training step of a denoiser (diff.py:113-118 / diff_graphset.py:64-75 run
     loss -> backward -> Adam on one device; here every rank does that on its own shard of the
@@ -177,13 +207,19 @@ class DataParallelTrainer:
     All gradients live in one flat fp32 bucket (the HIP backward kernels' outputs are accumulated
     into views of it).  With `overlap` (default) the bucket leaves in >= 4 MB chunks over RCCL while
     backward is still running -- 3 chunks for the mlp at D=512 (11 MB), 6 for ddpm.Backbone (25 MB);
-    otherwise as ONE all-reduce after backward.  The optimizer is torch's Adam on every rank
-    (identical updates: weights never need a broadcast after the first)."""
+    otherwise as ONE all-reduce after backward.  The optimizer is Adam on every rank (BucketAdam: one launch over the
+    bucket; torch.optim.Adam for host tensors or when passed in) -- identical updates: weights never need a broadcast
+    after the first."""
 
     def __init__(self, module, lr=1e-3, group=None, optimizer=None, broadcast=True, overlap=True):
         self.module, self.group, self.overlap = module, group, overlap
         self.bucket = GradBucket(module.parameters())
-        self.opt = optimizer if optimizer is not None else torch.optim.Adam(self.bucket.params, lr=lr)
+        if optimizer is not None:
+            self.opt = optimizer
+        elif self.bucket.params and all(p.is_cuda for p in self.bucket.params):
+            self.opt = BucketAdam(self.bucket, lr=lr)
+        else:                                     # host tensors (the gloo tests of the trainer's logic)
+            self.opt = torch.optim.Adam(self.bucket.params, lr=lr)
         if broadcast and _collective(group):
             src = dist.get_global_rank(group, 0) if group is not None else 0
             with torch.no_grad():

@@ -359,6 +359,16 @@ int hd_gemm_tn_f32(const void* A, const void* B, void* C, int64_t R, int64_t P, 
 int64_t hd_gemm_tn_bf16x3_workspace_floats(int64_t R, int64_t P, int64_t Q);
 int hd_gemm_tn_bf16x3_f32(const void* A, const void* B, void* C, void* colsum_a, int64_t R, int64_t P, int64_t Q,
                           int64_t lda, int64_t ldb, int64_t ldc, void* workspace, void* stream);
+/* optimizer.step() of optim.Adam(diff.parameters(), lr) (diff.py:107,117; diff_graphset.py:66,74; torch defaults: no weight
+ * decay, no amsgrad) for every parameter tensor in ONE launch: job i updates `count` fp32 elements at `param` from the
+ * gradient / first / second moment elements [offset, offset + count) of three flat fp32 arrays (the gradient bucket of
+ * the data-parallel trainer and two state arrays of the same layout).  `step` counts from 1.  At most 32 jobs. */
+typedef struct hd_adam_job {
+    void* param;
+    int64_t offset, count;
+} hd_adam_job;
+int hd_adam_step_f32(const hd_adam_job* jobs, int n_jobs, const void* grad_flat, void* exp_avg_flat, void* exp_avg_sq_flat,
+                     double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
 /* out[cols, rows] = in[rows, cols]^T */
 int hd_transpose_f32(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out,
                      void* stream);

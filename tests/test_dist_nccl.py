@@ -60,7 +60,9 @@ def _worker(port, q):
         noise = torch.from_numpy(rs.standard_normal((n, dim))).to(dev)
         import copy
         ref_mlp = copy.deepcopy(diff.mlp)
+        ref2_mlp = copy.deepcopy(diff.mlp)
         tr = hdist.DataParallelTrainer(diff.mlp, lr=1e-3)
+        tr.opt = torch.optim.Adam(tr.bucket.params, lr=1e-3)        # torch's Adam: the gradient path is bit-checked
         res["chunks"] = len(tr.bucket.chunks)
         loss_fn = lambda: diff(torch.from_numpy(emb).to(dev), None, labels, u0, restrict=True, graphset=True, t=t,
                                noise=noise.clone())
@@ -80,6 +82,16 @@ def _worker(port, q):
         res["trainer"] = all(torch.equal(a, b.detach()) for a, b in zip(mine, ref_mlp.parameters()))
         res["losses"] = losses == ref_losses and losses[2] < losses[0]
         hdist.FORCE_COLLECTIVES = True
+        # (2b) the default optimizer (BucketAdam, one launch): same trajectory as torch's Adam to rounding
+        diff.mlp = ref2_mlp
+        tr2 = hdist.DataParallelTrainer(ref2_mlp, lr=1e-3)
+        res["bucket_adam"] = isinstance(tr2.opt, hdist.BucketAdam)
+        v0 = [p._version for p in ref2_mlp.parameters()]
+        losses2 = [float(tr2.step(loss_fn)) for _ in range(3)]
+        res["bucket_adam_versions"] = all(p._version > v for p, v in zip(ref2_mlp.parameters(), v0))
+        res["bucket_adam_close"] = all(torch.allclose(a.detach(), b, rtol=1e-5, atol=2e-7) for a, b in
+                                       zip(ref2_mlp.parameters(), mine)) and \
+            np.allclose(losses2, ref_losses, rtol=1e-5)
         # (3) row-sharded encode: all-gather (whole, and pipelined in 4 column slabs) == unsharded encode
         g_n, feat, d = 3000, 16, 64
         adj = workloads.add_hubs(workloads.power_law_graph(g_n, 4), (600,))
