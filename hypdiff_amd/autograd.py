@@ -126,16 +126,19 @@ def gemm_limbs_train(a, w, bias, aux, epi, want_z=False, want_f32=True, want_lim
     M, K, N = a.rows, a.cols, w.rows
     assert w.cols == K, ((a.rows, a.cols), (w.rows, w.cols))
     dev = a.buf.device
-    z = torch.empty(M, N, dtype=torch.float32, device=dev) if want_z else None
-    c = torch.empty(M, N, dtype=torch.float32, device=dev) if want_f32 else None
+    # fp32 rows padded to 64 bytes: a lane quartet's 64-byte piece of a row is then one whole sector for the
+    # non-temporal stores of the write-out (N = 900, 700: unaligned rows measured 25 % slower launches)
+    ld = (N + 15) // 16 * 16
+    z = torch.empty(M, ld, dtype=torch.float32, device=dev)[:, :N] if want_z else None
+    c = torch.empty(M, ld, dtype=torch.float32, device=dev)[:, :N] if want_f32 else None
     cl = ops.limb_empty(M, N, dev, "bf16x3") if want_limbs else None
-    assert aux is None or (aux.is_contiguous() and tuple(aux.shape) == (M, N))
+    assert aux is None or (tuple(aux.shape) == (M, N) and aux.stride() == (ld, 1) and aux.data_ptr() % 16 == 0)
     ev = ops.GEMM_EVENTS
     if ev is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     _lib.call("hd_gemm_limbs_train_f32", ops._p(a.buf), ops._p(w.buf), ops._p(bias), ops._p(aux), ops._p(z), ops._p(c),
-              ops._p(cl.buf) if cl is not None else None, M, N, K, N, epi, ops._stream())
+              ops._p(cl.buf) if cl is not None else None, M, N, K, ld, epi, ops._stream())
     if ev is not None:
         e1.record()
         kp, npad = (K + 31) // 32 * 32, (N + 31) // 32 * 32

@@ -433,7 +433,7 @@ __device__ __forceinline__ void store_quad(float v[4], int m, int mloc, int nb, 
     if (Z) {                                                  // training: the pre-activation is kept for the backward pass
         float* zo = Z + (size_t)m * ldc + nb;
         if (vec && (!CHECK || nb + 3 < N)) {
-            *reinterpret_cast<float4*>(zo) = make_float4(v[0], v[1], v[2], v[3]);
+            __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(zo));
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -477,7 +477,8 @@ __device__ __forceinline__ void store_quad(float v[4], int m, int mloc, int nb, 
     if (C) {
         float* o = C + (size_t)m * ldc + nb;
         if (vec && (!CHECK || nb + 3 < N)) {
-            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            if (Z || epi == 3) __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(o));
+            else *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
