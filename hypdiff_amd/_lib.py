@@ -113,6 +113,7 @@ SIGNATURES = {
     "hd_gemm_f16x2_f32": [P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, c_int, c_float, c_float, P],
     "hd_gemm_tn_f32": [P, P, P, I64, I64, I64, I64, I64, I64, P, P],
     "hd_gemm_tn_bf16x3_f32": [P, P, P, P, I64, I64, I64, I64, I64, I64, P, P],
+    "hd_gemm_tn_limbs_f32": [P, P, P, P, I64, I64, I64, I64, P, P],
     "hd_transpose_f32": [P, P, I64, I64, I64, I64, P],
     "hd_adam_step_f32": [POINTER(HdAdamJob), c_int, P, P, P, c_double, c_double, c_double, c_double, I64, P],
     "hd_colsum_f32": [P, P, I64, I64, I64, P, P],

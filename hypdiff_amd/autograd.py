@@ -103,6 +103,39 @@ def _gemm_tn_cs(a, b, out, cs, want_cs=True):
     return out, cs
 
 
+def gemm_tn_limbs(a_img, b_img, out=None, colsum_out=None):
+    """(out[P,Q], colsum[P]) = (a^T @ b, colsum(a)) from the bf16x3 limb images of a (R, P) and b (R, Q)
+    (hd_gemm_tn_limbs_f32).  P, Q are the image widths rounded up to multiples of 4 (pad columns are zero in an image)."""
+    R = a_img.rows
+    assert b_img.rows == R and a_img.fmt == b_img.fmt == "bf16x3"
+    P, Q = (a_img.cols + 3) // 4 * 4, (b_img.cols + 3) // 4 * 4
+    dev = a_img.buf.device
+    if out is None or out.data_ptr() % 16 or not out.is_contiguous() or tuple(out.shape) != (P, Q):
+        res, cs = gemm_tn_limbs(a_img, b_img, torch.empty(P, Q, dtype=torch.float32, device=dev), None)
+        if out is None:
+            return res, cs
+        out.copy_(res[: out.shape[0], : out.shape[1]])
+        if colsum_out is not None:
+            colsum_out.copy_(cs[: colsum_out.shape[0]])
+        return out, colsum_out if colsum_out is not None else cs
+    own_cs = colsum_out is None or colsum_out.data_ptr() % 16 or not colsum_out.is_contiguous() or colsum_out.numel() != P
+    cs = torch.empty(P, dtype=torch.float32, device=dev) if own_cs else colsum_out
+    ws = _ws(_lib.load().hd_gemm_tn_bf16x3_workspace_floats(R, P, Q), torch.float32, dev)
+    ev = ops.GEMM_EVENTS
+    if ev is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.call("hd_gemm_tn_limbs_f32", ops._p(a_img.buf), ops._p(b_img.buf), ops._p(out), ops._p(cs), R, P, Q, out.stride(0),
+              ops._p(ws), ops._stream())
+    if ev is not None:
+        e1.record()
+        ev.append((e0, e1, 2.0 * R * P * Q, 6.0 * (R * P + R * Q) + 4.0 * P * Q))
+    if own_cs and colsum_out is not None:
+        colsum_out.copy_(cs[: colsum_out.numel()])
+        cs = colsum_out
+    return out, cs
+
+
 def transpose(w):
     out = torch.empty(w.shape[1], w.shape[0], dtype=torch.float32, device=w.device)
     _lib.call("hd_transpose_f32", ops._p(w), ops._p(out), w.shape[0], w.shape[1], w.stride(0), out.stride(0),
@@ -167,31 +200,31 @@ class LinearStack(torch.autograd.Function):
         assert len(ws_) == len(kinds) == len(bs_)
         ctx.limbs = _limb_stack_ok(x, kinds, ws_)
         if ctx.limbs:
-            # operands travel as bf16x3 limb images (split once per element by the producing GEMM's write-out);
-            # fp32 copies are written where the backward pass reads them: z (gelu') and x_l (weight gradient)
-            xs, zs = [x], []
+            # operands travel as bf16x3 limb images (split once per element by the producing GEMM's write-out) and the
+            # backward pass reads the same images (the weight gradient contracts over image rows): the only fp32
+            # activations kept are the pre-activations z (gelu')
+            zs, a_imgs = [], []
             # the input, every W_l and (for the input gradients of the backward pass) every W_l^T above the first
             # layer become limb images in ONE launch: the weights change every step, so nothing can be cached
             L = len(kinds)
-            train = any(w.requires_grad for w in ws_)
+            train = any(p.requires_grad for p in params)
             imgs = ops.limb_pack_multi([(x[:, : ws_[0].shape[1]], False)] + [(w.detach(), False) for w in ws_] +
                                        ([(w.detach(), True) for w in ws_[1:]] if train else []))
             a, wimgs = imgs[0], imgs[1:1 + L]
             ctx.wt_imgs = [None] + imgs[1 + L:] if train else None
-            h = x
+            h = None
             for l, kind in enumerate(kinds):
-                last = l == len(kinds) - 1
-                wl = wimgs[l]
-                z, h, a = gemm_limbs_train(a, wl, bs_[l].detach(), None, 1 if kind == GELU else 0, want_z=kind == GELU,
-                                           want_limbs=not last)
+                last = l == L - 1
+                a_imgs.append(a)
+                z, h, a = gemm_limbs_train(a, wimgs[l], bs_[l].detach(), None, 1 if kind == GELU else 0,
+                                           want_z=kind == GELU and train, want_f32=last, want_limbs=not last)
                 zs.append(z)
-                if not last:
-                    xs.append(h)
+            ctx.x_imgs = a_imgs if train else None
             ctx.kinds = kinds
             ctx.params = params
             ctx.need_x = False
             ctx.wshapes = [tuple(w.shape) for w in ws_]
-            ctx.save_for_backward(*xs, *[z for z in zs if z is not None], *[w.detach() for w in ws_])
+            ctx.save_for_backward(*[z for z in zs if z is not None])
             ctx.nz = [z is not None for z in zs]
             return h
         xs, zs, wpad = [], [], []
@@ -218,6 +251,8 @@ class LinearStack(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         kinds, L = ctx.kinds, len(ctx.kinds)
+        if ctx.limbs:
+            return LinearStack._backward_limbs(ctx, gy)
         saved = list(ctx.saved_tensors)
         xs = saved[:L]
         nzc = sum(ctx.nz)
@@ -253,14 +288,6 @@ class LinearStack(torch.autograd.Function):
                 grads[2 * l] = dw if tuple(dw.shape) == shp else dw[:, :shp[1]].contiguous()
             if l == 0 and not ctx.need_x:
                 break
-            if ctx.limbs:
-                # dz_below = (dz @ W_l) * gelu'(z_below) on the limb GEMM: dz as an image (the one below is written
-                # by this launch's write-out), W_l^T split once per step
-                if l == top:
-                    dz_img = ops.limb_pack(dz, "bf16x3")
-                wt_img = ctx.wt_imgs[l] if ctx.wt_imgs is not None else ops.limb_pack_multi([(w, True)])[0]
-                _, dz, dz_img = gemm_limbs_train(dz_img, wt_img, None, zs[l - 1], 3, want_limbs=l - 1 >= 1)
-                continue
             wt = transpose(w)                                    # (K_l, N_l): contraction over N_l
             M, Kl = x_l.shape
             resid = g_up if kinds[l] == RES else None
@@ -276,6 +303,39 @@ class LinearStack(torch.autograd.Function):
             g_up, dz = g, dz_below
         gx = g_up if ctx.need_x else None
         return (gx, None, *grads)
+
+    @staticmethod
+    def _backward_limbs(ctx, gy):
+        """Backward pass on limb images only: dz travels down as an image (written by the input-gradient launch's
+        write-out, (dz @ W_l) * gelu'(z_below)); dW_l = dz^T x_l and db_l = colsum(dz) come from the dz image and the
+        image of x_l that the forward pass fed to layer l (hd_gemm_tn_limbs_f32), straight into the gradient bucket
+        when one is armed."""
+        kinds, L = ctx.kinds, len(ctx.kinds)
+        zl = iter(ctx.saved_tensors)
+        zs = [next(zl) if has else None for has in ctx.nz]
+        if kinds[L - 1] != LIN:
+            raise NotImplementedError("LinearStack: the last layer must be linear")
+        grads = [None] * (2 * L)
+        dz_img = ops.limb_pack(gy.contiguous(), "bf16x3")
+        sink = GRAD_SINK
+        for l in range(L - 1, -1, -1):
+            shp = ctx.wshapes[l]
+            wp, bp = ctx.params[2 * l], ctx.params[2 * l + 1]
+            wv = sink.view_for(wp) if sink is not None else None
+            bv = sink.view_for(bp) if sink is not None else None
+            if wv is not None and bv is not None:
+                gemm_tn_limbs(dz_img, ctx.x_imgs[l], out=wv, colsum_out=bv)
+                sink.delivered(bp)
+                sink.delivered(wp)
+            else:
+                dw, db = gemm_tn_limbs(dz_img, ctx.x_imgs[l])
+                grads[2 * l] = dw if tuple(dw.shape) == shp else dw[: shp[0], : shp[1]].contiguous()
+                grads[2 * l + 1] = db if db.numel() == shp[0] else db[: shp[0]].contiguous()
+            if l == 0:
+                break
+            _, _, dz_img = gemm_limbs_train(dz_img, ctx.wt_imgs[l], None, zs[l - 1], 3, want_f32=False, want_limbs=True)
+        ctx.x_imgs = ctx.wt_imgs = None
+        return (None, None, *grads)
 
 
 def linear_stack(x, layers, kinds):

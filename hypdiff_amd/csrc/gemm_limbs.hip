@@ -688,7 +688,23 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_limbs(const uint4* __restrict
                 for (int i = 0; i < MT; ++i) {
                     const int mloc = wr * 64 + i * 16 + r16;
                     const int m = m0 + mloc;
-                    if (CHECK && m >= M) continue;
+                    if (CHECK && m >= M) {
+                        // pad rows of the last row block: ZERO in the output image (the weight gradient contracts over
+                        // image rows, hd_gemm_tn_limbs_f32), nothing else is written
+                        if (CL) {
+#pragma unroll
+                            for (int j = 0; j < NT16; ++j) {
+                                const int nb = n0 + wc * WCOLS + j * 16 + 4 * kq;
+                                if (nb >= nout) continue;
+                                uint2* o = reinterpret_cast<uint2*>(CL + cl_base + (size_t)(nb >> 5) * kTile + ((nb & 31) >> 3) * 128 +
+                                                                    mloc) + (kq & 1);
+                                o[0] = make_uint2(0u, 0u);
+                                o[2 * 4 * 128] = make_uint2(0u, 0u);
+                                if constexpr (!F16) o[2 * 8 * 128] = make_uint2(0u, 0u);
+                            }
+                        }
+                        continue;
+                    }
                     int ea_m = 0, eo_m = 0;
                     float rmax = 0.f;
                     if constexpr (F16) {

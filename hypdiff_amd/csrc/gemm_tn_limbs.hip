@@ -145,6 +145,134 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16x3(const float* __restrict__ 
     }
 }
 
+// The same product from the limb IMAGES that the forward and input-gradient launches write anyway (bf16x3,
+// [row block 128][slab 32][limb][kc][row] chunks of 8 columns of one row): no fp32 copies of dz or of the layer inputs
+// exist in training, and nothing is split here.  The contraction runs over image ROWS, while a chunk holds 8 COLUMNS of
+// one row -- the transpose is gfx950's ds_read_b64_tr_b16: a slab of 32 rows goes to LDS by LDS-DMA as 48 sub-tiles
+// [32 rows][16 columns] of 1 KB (operand, 32-column slab, limb, column half), and a 16-lane group reads a 4-row x
+// 16-column block of one and receives it column-major, i.e. 4 consecutive k of its own column: two reads make one
+// v_mfma_f32_16x16x32_bf16 operand.  Rows sit in the sub-tile in the order (bit 2 <-> bit 3 swapped), so that the 32
+// lanes of a half-wavefront (rows 8g..8g+3 of two groups, 32 bytes each) cover one 256-byte bank row: conflict-free.
+// The pad rows of the last 128-row block must be ZERO in both images (hd_limb_pack*_f32 and the limb GEMM's write-out
+// zero them).  The bias gradient is three extra multiplies per 16 columns with an all-ones operand in the first tile column.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+struct Frag8 { s16x4 lo, hi; };
+
+__device__ __forceinline__ lbf16x8 tr_frag(const __attribute__((address_space(3))) char* base, int imm) {
+    Frag8 f;
+    f.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        reinterpret_cast<__attribute__((address_space(3))) s16x4*>(const_cast<__attribute__((address_space(3))) char*>(base + imm)));
+    f.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        reinterpret_cast<__attribute__((address_space(3))) s16x4*>(const_cast<__attribute__((address_space(3))) char*>(base + imm + 256)));
+    return __builtin_bit_cast(lbf16x8, f);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_img(const uint4* __restrict__ Aimg, const uint4* __restrict__ Bimg,
+                                                   float* __restrict__ out, int R, int P, int Q, int ldo, int chunk,
+                                                   int tiles_q, int tiles, int total, size_t slice_stride,
+                                                   float* __restrict__ cs_out) {
+    __shared__ __attribute__((aligned(1024))) uint4 lds[48 * 64];  // [operand][slab][limb][column half][32 rows x 16 columns]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per_xcd = (gridDim.x + 7) >> 3;
+    const int vid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (vid >= total) return;                                     // uniform
+    const int tile = vid % tiles, slice = vid / tiles;
+    const int tp = tile / tiles_q, tq = tile - tp * tiles_q;
+    const int p0 = tp * TP, q0 = tq * TQ;
+    const int r_begin = slice * chunk, r_end = r_begin + chunk < R ? r_begin + chunk : R;
+    const int nslab = (r_end - r_begin + TR - 1) / TR;
+    // staging: wavefront w brings sub-tiles 12 w .. 12 w + 11 (waves 0, 1: A; 2, 3: B); lane L fetches the chunk of column
+    // half L & 1, row swap23(L >> 1) of the slab, into position L of the sub-tile
+    const int op = wave >> 1;
+    const uint4* img = op ? Bimg : Aimg;
+    const int nsl_img = ((op ? Q : P) + 31) >> 5, s0 = (op ? q0 : p0) >> 5;
+    const int slot = lane >> 1;
+    const int row_l = (slot & 19) | ((slot & 4) << 1) | ((slot & 8) >> 1);
+    unsigned lane_off[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const int rem = (wave & 1) * 12 + k;                     // (slab * 3 + limb) * 2 + column half, within the operand
+        const int sl = rem / 6, l = (rem % 6) >> 1, kp = rem & 1;
+        int sg = s0 + sl;
+        sg = sg < nsl_img ? sg : nsl_img - 1;                    // beyond the image: any valid slab (columns never written out)
+        lane_off[k] = (unsigned)(sg * 1536 + l * 512 + (2 * kp + (lane & 1)) * 128 + row_l);
+    }
+    auto stage = [&](int t) {
+        const int r = r_begin + t * TR;
+        const uint4* base = img + ((size_t)(r >> 7) * nsl_img * 1536 + (r & 127));
+#pragma unroll
+        for (int k = 0; k < 12; ++k) limb_glds16(base + lane_off[k], lds + (wave * 12 + k) * 64);
+    };
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lane_base = (((kq >> 1) * 16 + (kq & 1) * 4 + (r16 >> 2)) * 32) + 8 * (r16 & 3);
+    const auto* lbase = (const __attribute__((address_space(3))) char*)lds;
+    const auto* a_base = lbase + lane_base + wr * 12288;
+    const auto* b_base = lbase + lane_base + 24576 + wc * 12288;
+    lf32x4 acc[4][4], csa[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        csa[i] = lf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = lf32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_cs = cs_out != nullptr && tq == 0 && wc == 0;  // uniform over the wavefront
+    const lbf16x8 ones = __builtin_bit_cast(lbf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
+    if (nslab > 0) stage(0);
+    for (int t = 0; t < nslab; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                          // the slab is in LDS
+        lbf16x8 fa[4][3], fb[4][3];
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int imm = ((i >> 1) * 6 + l * 2 + (i & 1)) * 1024;
+                fa[i][l] = tr_frag(a_base, imm);
+                fb[i][l] = tr_frag(b_base, imm);
+            }
+        __syncthreads();                                          // every wavefront holds its fragments: buffer free
+        if (t + 1 < nslab) stage(t + 1);                          // in flight during the multiplies
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lf32x4 c = acc[i][j];
+#define HD_MM(bl, al) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][bl], fa[i][al], c, 0, 0, 0);
+                HD_MM(0, 2) HD_MM(2, 0) HD_MM(1, 1) HD_MM(0, 1) HD_MM(1, 0) HD_MM(0, 0)
+#undef HD_MM
+                acc[i][j] = c;
+            }
+            if (do_cs) {
+                lf32x4 c = csa[i];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[i][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[i][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[i][0], c, 0, 0, 0);
+                csa[i] = c;
+            }
+        }
+    }
+    if (do_cs && kq == 0) {                                       // every row of the ones product is the column sum
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = p0 + wr * 64 + i * 16 + r16;
+            if (p < P) cs_out[(size_t)slice * P + p] = csa[i][0];
+        }
+    }
+    float* o = out + (size_t)slice * slice_stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = p0 + wr * 64 + i * 16 + r16;
+        if (p >= P) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = q0 + wc * 64 + j * 16 + 4 * kq;
+            if (q < Q)
+                *reinterpret_cast<float4*>(o + (size_t)p * ldo + q) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    }
+}
+
 // out[i] = sum over slices, in slice order; the column sums (count2 of them per slice, 0 = none) follow the tiles
 __global__ __launch_bounds__(256) void tn_reduce(const float* __restrict__ ws, int nsl, size_t count, float* __restrict__ out,
                                                  const float* __restrict__ ws2, size_t count2, float* __restrict__ out2) {
@@ -215,4 +343,47 @@ extern "C" int hd_gemm_tn_bf16x3_f32(const void* A, const void* B, void* C, void
                                                                                (float*)colsum_a);
     }
     return check_launch("hd_gemm_tn_bf16x3_f32");
+}
+
+extern "C" int hd_gemm_tn_limbs_f32(const void* Aimg, const void* Bimg, void* C, void* colsum_a, int64_t R, int64_t P,
+                                    int64_t Q, int64_t ldc, void* workspace, void* st) {
+    HD_REQUIRE(R >= 0 && P >= 1 && Q >= 1, "hd_gemm_tn_limbs_f32: bad shape R=%lld P=%lld Q=%lld", (long long)R, (long long)P,
+               (long long)Q);
+    HD_REQUIRE(C && (R == 0 || (Aimg && Bimg)), "hd_gemm_tn_limbs_f32: null pointer");
+    HD_REQUIRE(R < (1LL << 31) && P < (1LL << 24) && Q < (1LL << 24), "hd_gemm_tn_limbs_f32: size exceeds the index range");
+    HD_REQUIRE(P % 4 == 0 && Q % 4 == 0 && ldc % 4 == 0 && ldc >= Q && is_aligned16(C) && is_aligned16(Aimg) && is_aligned16(Bimg),
+               "hd_gemm_tn_limbs_f32: P, Q, ldc must be multiples of 4 and the images and C 16-byte aligned");
+    HD_REQUIRE(!colsum_a || is_aligned16(colsum_a), "hd_gemm_tn_limbs_f32: colsum_a must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)st;
+    if (R == 0) {
+        HD_REQUIRE(ldc == Q, "hd_gemm_tn_limbs_f32: empty reduction needs a contiguous output");
+        if (hipMemsetAsync(C, 0, (size_t)P * Q * sizeof(float), s) != hipSuccess ||
+            (colsum_a && hipMemsetAsync(colsum_a, 0, (size_t)P * sizeof(float), s) != hipSuccess))
+            return check_launch("hd_gemm_tn_limbs_f32");
+        return HD_OK;
+    }
+    const int tiles_p = (int)((P + TP - 1) / TP), tiles_q = (int)((Q + TQ - 1) / TQ);
+    const int tiles = tiles_p * tiles_q;
+    const int splits = host_slices(R, tiles);
+    int chunk = (int)((R + splits - 1) / splits);
+    chunk = (chunk + TR - 1) / TR * TR;
+    const int nsl = (int)((R + chunk - 1) / chunk);
+    HD_REQUIRE((int64_t)tiles * nsl < (1LL << 31), "hd_gemm_tn_limbs_f32: too many workgroups");
+    const unsigned grid = (unsigned)((tiles * nsl + 7) / 8 * 8);
+    if (nsl > 1) {
+        HD_REQUIRE(workspace && is_aligned16(workspace), "hd_gemm_tn_limbs_f32: workspace of hd_gemm_tn_bf16x3_workspace_floats() floats required");
+        HD_REQUIRE(ldc == Q, "hd_gemm_tn_limbs_f32: split reduction needs a contiguous output (ldc == Q)");
+        const size_t count = (size_t)P * Q;
+        float* cs_ws = colsum_a ? (float*)workspace + (size_t)nsl * count : nullptr;
+        gemm_tn_img<<<dim3(grid), 256, 0, s>>>((const uint4*)Aimg, (const uint4*)Bimg, (float*)workspace, (int)R, (int)P, (int)Q,
+                                               (int)Q, chunk, tiles_q, tiles, tiles * nsl, count, cs_ws);
+        const size_t count2 = colsum_a ? (size_t)P : 0;
+        int blocks = (int)(((count + count2) / 4 + 255) / 256);
+        blocks = blocks < 2048 ? blocks : 2048;
+        tn_reduce<<<blocks, 256, 0, s>>>((const float*)workspace, nsl, count, (float*)C, cs_ws, count2, (float*)colsum_a);
+    } else {
+        gemm_tn_img<<<dim3(grid), 256, 0, s>>>((const uint4*)Aimg, (const uint4*)Bimg, (float*)C, (int)R, (int)P, (int)Q, (int)ldc,
+                                               chunk, tiles_q, tiles, tiles, 0, (float*)colsum_a);
+    }
+    return check_launch("hd_gemm_tn_limbs_f32");
 }

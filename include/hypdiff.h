@@ -369,6 +369,14 @@ typedef struct hd_adam_job {
 } hd_adam_job;
 int hd_adam_step_f32(const hd_adam_job* jobs, int n_jobs, const void* grad_flat, void* exp_avg_flat, void* exp_avg_sq_flat,
                      double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
+/* The same weight gradient (and bias gradient) from bf16x3 limb IMAGES of A (R x P) and B (R x Q) -- the images the
+ * forward and input-gradient launches of hd_gemm_limbs_train_f32 write anyway, so training keeps no fp32 copies of dz or
+ * of the layer inputs.  The contraction runs over image rows (LDS-DMA + ds_read_b64_tr_b16 transposing reads); the pad
+ * rows of the last 128-row block must be zero in both images (hd_limb_pack*_f32 and the limb GEMM's write-out zero them).
+ * P, Q multiples of 4 with ceil(P/32), ceil(Q/32) the images' slab counts; C 16-byte aligned, contiguous when the rows
+ * are split; workspace of hd_gemm_tn_bf16x3_workspace_floats(R,P,Q) floats. */
+int hd_gemm_tn_limbs_f32(const void* Aimg, const void* Bimg, void* C, void* colsum_a, int64_t R, int64_t P, int64_t Q,
+                         int64_t ldc, void* workspace, void* stream);
 /* out[cols, rows] = in[rows, cols]^T */
 int hd_transpose_f32(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out,
                      void* stream);

@@ -396,6 +396,44 @@ def test_hip_gemm_tn_shapes(R, P, Q, mode, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("R,P,Q", [(1, 4, 4), (31, 8, 132), (64, 128, 128), (257, 900, 516), (1000, 14, 17),
+                                   (5000, 260, 68), (15777, 64, 512), (15777, 800, 513), (15777, 900, 800)])
+def test_hip_gemm_tn_limbs_shapes(R, P, Q):
+    """hd_gemm_tn_limbs_f32: dW = A^T B and db = colsum(A) from bf16x3 limb IMAGES (transposing LDS reads), over ragged
+    row blocks / slices / tiles: exact on small-integer data, within fp32 reassociation on Gaussian data, reproducible,
+    and pad rows of an image written by the limb GEMM's write-out are zero (the contraction runs over them)."""
+    from hypdiff_amd import autograd as hag, ops
+    rs = np.random.RandomState(R + P + Q)
+    a = rs.randint(-3, 4, size=(R, P)).astype(np.float32)
+    b = rs.randint(-3, 4, size=(R, Q)).astype(np.float32)
+    pack = lambda x: ops.limb_pack(torch.from_numpy(x).cuda(), "bf16x3")
+    got, cs = hag.gemm_tn_limbs(pack(a), pack(b))
+    assert np.array_equal(got.cpu().numpy()[:P, :Q], (a.astype(np.float64).T @ b.astype(np.float64)).astype(np.float32))
+    assert not got.cpu().numpy()[P:].any() and not got.cpu().numpy()[:, Q:].any()
+    assert np.array_equal(cs.cpu().numpy()[:P], a.sum(0, dtype=np.float64).astype(np.float32))
+    a, b = rs.standard_normal((R, P)).astype(np.float32), rs.standard_normal((R, Q)).astype(np.float32)
+    ai, bi = pack(a), pack(b)
+    got, cs = hag.gemm_tn_limbs(ai, bi)
+    want = a.astype(np.float64).T @ b.astype(np.float64)
+    bound = 2e-6 * (np.abs(a).astype(np.float64).T @ np.abs(b).astype(np.float64))
+    assert (np.abs(got.cpu().numpy()[:P, :Q] - want) <= bound + 1e-30).all()
+    assert (np.abs(cs.cpu().numpy()[:P] - a.sum(0, dtype=np.float64)) <= 2e-6 * np.abs(a).sum(0, dtype=np.float64)).all()
+    got2, cs2 = hag.gemm_tn_limbs(ai, bi)
+    assert torch.equal(got2, got) and torch.equal(cs2, cs)
+    if R % 128 and P % 4 == 0:
+        # the image of a GEMM product: poison the buffer first, then the write-out must have zeroed the pad rows
+        K = 64
+        x = torch.from_numpy(rs.standard_normal((R, K)).astype(np.float32)).cuda()
+        w = torch.from_numpy(rs.standard_normal((P, K)).astype(np.float32)).cuda()
+        torch.empty(1 << 24, dtype=torch.int32, device="cuda").fill_(0x7fc07fc0)       # NaN limbs into the allocator's cache
+        _, c, cl = hag.gemm_limbs_train(ops.limb_pack(x), ops.limb_pack(w), None, None, 0, want_f32=True, want_limbs=True)
+        got, _ = hag.gemm_tn_limbs(cl, bi)
+        want = c.double().cpu().numpy().T @ b.astype(np.float64)
+        bound = 2e-6 * (np.abs(c.double().cpu().numpy()).T @ np.abs(b).astype(np.float64))
+        assert (np.abs(got.cpu().numpy()[:P, :Q] - want) <= bound + 1e-30).all()
+
+
+@pytest.mark.gpu
 def test_hip_limb_pack_multi_matches_single():
     """hd_limb_pack_multi_f32 (all weight images of a training step in one launch, W and W^T) writes the same bytes
     as hd_limb_pack_f32 of the matrix / of hd_transpose_f32's output; 17 jobs = two launches; ragged shapes."""

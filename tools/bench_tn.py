@@ -34,6 +34,23 @@ def main():
             us = e0.elapsed_time(e1) * 1e3 / reps
             tot[mode] = tot.get(mode, 0.0) + us
             print(f"{mode:7s} {R}x{P}x{Q}: {us:7.1f} us  {2.0 * R * P * Q / us * 1e-6:6.1f} TFLOP/s", flush=True)
+    for P, Q in shapes:                                   # the same products from limb images (hd_gemm_tn_limbs_f32)
+        ai = ops.limb_pack(torch.randn(R, P, device="cuda", generator=g), "bf16x3")
+        bi = ops.limb_pack(torch.randn(R, Q, device="cuda", generator=g), "bf16x3")
+        Pp, Qp = (P + 3) // 4 * 4, (Q + 3) // 4 * 4
+        out = torch.empty(Pp, Qp, device="cuda")
+        cs = torch.empty(Pp, device="cuda")
+        for _ in range(5):
+            hag.gemm_tn_limbs(ai, bi, out=out, colsum_out=cs)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            hag.gemm_tn_limbs(ai, bi, out=out, colsum_out=cs)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        tot["images"] = tot.get("images", 0.0) + us
+        print(f"images  {R}x{P}x{Q}: {us:7.1f} us  {2.0 * R * P * Q / us * 1e-6:6.1f} TFLOP/s", flush=True)
     print({k: round(v, 1) for k, v in tot.items()})
 
 
