@@ -123,6 +123,8 @@ SIGNATURES = {
     "hd_mse_backward_f32": [P, P, P, I64, P],
     "hd_q_sample": [P, c_int, P, c_int, P, P, P, I64, P, P, I64, P, I64, I64, c_int, c_double, c_double,
                     c_double, P],
+    "hd_q_sample_pack_train": [P, P, P, c_int, c_int, P, P, P, P, I64, P, P, I64, P, P, I64, I64, I64, c_double, c_double,
+                               c_double, P],
     "hd_p_sample_update": [P, c_int, P, P, P, I64, c_double, c_double, c_double, c_double, I64, I64, P, I64,
                            I64, c_double, c_double, c_double, P],
     "hd_tran_direction": [P, c_int, P, P, I64, I64, I64, P],

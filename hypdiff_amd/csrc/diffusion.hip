@@ -47,6 +47,49 @@ __global__ __launch_bounds__(256) void q_sample_k(const TX* __restrict__ x0, TN*
     }
 }
 
+// The training forward's three passes between the moments and the denoiser in one (:145-149 normalization,
+// :198-213 q_sample with tran_direction, :57-58 the mlp's cat(x.float(), t)): x_start = (x - mean) / std in fp64, kept
+// as fp32 for the loss (:362 casts it); x_t from x_start, the direction-constrained noise and the prior; the mlp's packed
+// fp32 input row [x_t.float(), t / T, 0 ...].  Every expression is the one of standardize_k / q_sample_k /
+// pack_input_k, so the results are bit-identical to the three launches.  The noise is written back (sign-flipped in
+// place, as tran_direction does) only when the caller owns it.
+template <typename TN>
+__global__ __launch_bounds__(256) void q_sample_pack_k(const double* __restrict__ x, const double* __restrict__ m,
+                                                       TN* __restrict__ noise, int write_noise,
+                                                       const int64_t* __restrict__ t, const float* __restrict__ t_col,
+                                                       const int32_t* __restrict__ labels,
+                                                       const float* __restrict__ signs, int64_t n_centres,
+                                                       const double* __restrict__ sqrt_ac,
+                                                       const double* __restrict__ sqrt_1mac, int64_t T,
+                                                       float* __restrict__ x_start, float* __restrict__ h, int64_t ldh,
+                                                       int64_t rows, int64_t dim, float sqrt_c, float horizon, float prior) {
+    const double n = m[2], mean = m[0] / n;
+    const double var = (m[1] - m[0] * m[0] / n) / (n - 1.0);
+    const double sd = sqrt(var > 0.0 ? var : 0.0);
+    const double mul = 1.0 / sd, add = -mean / sd;
+    const int64_t total = rows * dim;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / dim, c = i - r * dim;
+        const int64_t traw = t[r];
+        const int64_t tt = traw < 0 ? 0 : (traw >= T ? T - 1 : traw);
+        int32_t lb = labels[r];
+        lb = lb < 0 ? 0 : (lb >= n_centres ? (int32_t)n_centres - 1 : lb);
+        const TN nz = (TN)(noise[i] * (TN)signs[(int64_t)lb * dim + c]);
+        if (write_noise) noise[i] = nz;
+        const double xs = fma(x[i], mul, add);
+        x_start[i] = (float)xs;
+        const float pri = getpri(traw, sqrt_c, horizon, prior);
+        const double px = (double)pri * xs;
+        const double xt = sqrt_ac[tt] * xs + sqrt_1mac[tt] * (double)nz + px;
+        float* hr = h + r * ldh;
+        hr[c] = (float)xt;
+        if (c == 0) {
+            hr[dim] = t_col[r];
+            for (int64_t e = dim + 1; e < ldh; ++e) hr[e] = 0.f;
+        }
+    }
+}
+
 // p_sample after the denoiser, :248-291:
 //   eps = ((sqrt(1/acp_t) + pri_t) * x_t - x0_raw) / sqrt(1/acp_t - 1)     (:230-236, unclamped x0)
 //   x0  = clamp(x0_raw, -1, 1)                                           (:266-267, in place)
@@ -303,6 +346,29 @@ extern "C" int hd_q_sample(const void* x0, int x_dtype, void* noise, int noise_d
     else QS(double, double);
 #undef QS
     return check_launch("hd_q_sample");
+}
+
+extern "C" int hd_q_sample_pack_train(const void* x, const void* moments3, void* noise, int noise_dtype, int write_noise,
+                                      const int64_t* t, const float* t_col, const int32_t* labels, const float* signs, int64_t n_centres,
+                                      const double* sqrt_ac, const double* sqrt_1mac, int64_t T, void* x_start,
+                                      void* h, int64_t ldh, int64_t rows, int64_t dim, double sqrt_c, double horizon,
+                                      double prior, void* st) {
+    HD_REQUIRE(rows >= 0 && dim >= 1 && T >= 1 && ldh >= dim + 1, "hd_q_sample_pack_train: bad shape rows=%lld dim=%lld T=%lld ldh=%lld",
+               (long long)rows, (long long)dim, (long long)T, (long long)ldh);
+    if (rows == 0) return HD_OK;
+    HD_REQUIRE(x && moments3 && noise && t && t_col && labels && signs && n_centres >= 1 && sqrt_ac && sqrt_1mac && x_start && h,
+               "hd_q_sample_pack_train: null pointer");
+    const int g = ew_grid(rows * dim);
+    hipStream_t s = (hipStream_t)st;
+    if (noise_dtype)
+        q_sample_pack_k<double><<<g, 256, 0, s>>>((const double*)x, (const double*)moments3, (double*)noise, write_noise, t,
+                                                  t_col, labels, signs, n_centres, sqrt_ac, sqrt_1mac, T, (float*)x_start, (float*)h,
+                                                  ldh, rows, dim, (float)sqrt_c, (float)horizon, (float)prior);
+    else
+        q_sample_pack_k<float><<<g, 256, 0, s>>>((const double*)x, (const double*)moments3, (float*)noise, write_noise, t,
+                                                 t_col, labels, signs, n_centres, sqrt_ac, sqrt_1mac, T, (float*)x_start, (float*)h,
+                                                 ldh, rows, dim, (float)sqrt_c, (float)horizon, (float)prior);
+    return check_launch("hd_q_sample_pack_train");
 }
 
 extern "C" int hd_p_sample_update(const void* x_t, int x_dtype, float* x0, const int32_t* labels,

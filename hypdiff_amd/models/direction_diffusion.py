@@ -176,6 +176,14 @@ class mlp(nn.Module):
         h = torch.empty(n, ld, dtype=torch.float32, device=x.device)
         ops._lib.call("hd_mlp_pack_input", ops._p(x), 1 if x.dtype == torch.float64 else 0, ops._p(tp), kind, ts,
                       ops._p(h), n, d, ld, ops._stream())
+        return self.forward_packed(h, d)
+
+    def forward_packed(self, h, d):
+        """the stack on an already packed input: h = [x.float(), t, 0 ...] rows of pitch (d + 1) rounded up to 4"""
+        ld = h.shape[1]
+        chain = [(self.fc1.weight, self.fc1.bias, 1), (self.fc2.weight, self.fc2.bias, 1),
+                 (self.fc3.weight, self.fc3.bias, 1), (self.fc4.weight, self.fc4.bias, 1),
+                 (self.fc5.weight, self.fc5.bias, 0)]
         if hag.wants_grad(*self.parameters()):
             # training (diff.py:113-118): forward and backward on HIP kernels, autograd only links them
             return hag.linear_stack(h, [self.fc1, self.fc2, self.fc3, self.fc4, self.fc5],
@@ -428,6 +436,8 @@ class diffusion(nn.Module):
         centres = u0 if torch.is_tensor(u0) else torch.stack(list(u0))
         return ops.map_at("hd_pb_expmap_at", centres, lab, ret, 1.0)
 
+    fuse_prepass = True      # training forward: normalization + q_sample + input concat as one launch (same bits)
+
     def forward(self, x, adj, labels, u0, restrict=True, graphset=False, t=None, noise=None):
         """:335-363 training loss; differentiable w.r.t. the denoiser parameters
         (loss.backward() runs hd_gemm_tn_f32 / hd_gemm_f32_ex kernels, hypdiff_amd/autograd.py).
@@ -435,12 +445,32 @@ class diffusion(nn.Module):
         x = x.to(torch.float64)
         b, n = x.shape
         t = torch.randint(0, self.num_timesteps, (b,), device=x.device).long() if t is None else t
+        own_noise = noise is not None                 # the caller's tensor: tran_direction flips its signs in place
         noise = torch.randn_like(x) if noise is None else noise
         direction = self.directions(u0)
         if not restrict:
             x_start = self.manifold.logmap0(x, c=1.0)
         else:
             x_start = self._logmap_centres(x, labels, u0)
+        if self.fuse_prepass and graphset and x_start.dtype == torch.float64 and t.dtype == torch.int64 and noise.is_contiguous() \
+                and noise.dtype in (torch.float32, torch.float64) and tuple(noise.shape) == (b, n) and b > 0:
+            # normalization, q_sample and the mlp's input concat in one pass (hd_q_sample_pack_train: the same
+            # expressions, bit-identical to the three launches below); the loss target comes out as fp32
+            ops._dev(x_start, t, noise)
+            x_start = x_start.contiguous()
+            m = self.moments(x_start)
+            signs = self._signs(direction)
+            lab = ops.labels_dev(labels, x.device)
+            ld = (n + 1 + 3) // 4 * 4
+            target = torch.empty(b, n, dtype=torch.float32, device=x.device)
+            h = torch.empty(b, ld, dtype=torch.float32, device=x.device)
+            tcol = (t / self.num_timesteps).to(torch.float32).contiguous()
+            ops._lib.call("hd_q_sample_pack_train", ops._p(x_start), ops._p(m), ops._p(noise),
+                          1 if noise.dtype == torch.float64 else 0, 1 if own_noise else 0, ops._p(t.contiguous()), ops._p(tcol),
+                          ops._p(lab), ops._p(signs), signs.shape[0], ops._p(self.sqrt_alphas_cumprod),
+                          ops._p(self.minus_alphas_cumprod), self.num_timesteps, ops._p(target), ops._p(h), ld, b, n,
+                          float(np.sqrt(self.c)), float(self.prior_horizon), float(self.prior), ops._stream())
+            return hag.mse_loss(self.mlp.forward_packed(h, n), target)
         x_start = self.normalization(x_start)
         xt = self.q_sample(x_start=x_start, t=t, direction=direction, noise=noise, labels=labels, u0=u0,
                            restrict=True)

@@ -410,6 +410,15 @@ int hd_q_sample(const void* x0, int x_dtype, void* noise, int noise_dtype, const
                 const int32_t* labels, const float* signs, int64_t n_centres, const double* sqrt_ac,
                 const double* sqrt_1mac, int64_t T, double* out, int64_t rows, int64_t dim, int restrict_,
                 double sqrt_c, double horizon, double prior, void* stream);
+/* The training forward between the moments and the denoiser in one pass (diffusion.forward :335-363 with graphset):
+ * normalization (:145-149) with the given {sum, sumsq, count}, q_sample with restrict (:198-213), and the mlp's
+ * cat(x_t.float(), t_col) (:57-58; t_col = t / T as the caller's fp32 tensor).  x fp64 (rows, dim); outputs: x_start as fp32 (the loss target, :362) and the packed
+ * fp32 input rows h (row pitch ldh >= dim + 1, zero padded).  Bit-identical to hd_standardize + hd_q_sample +
+ * hd_mlp_pack_input.  noise is sign-flipped in place only when write_noise is set (the caller owns it). */
+int hd_q_sample_pack_train(const void* x, const void* moments3, void* noise, int noise_dtype, int write_noise,
+                           const int64_t* t, const float* t_col, const int32_t* labels, const float* signs, int64_t n_centres,
+                           const double* sqrt_ac, const double* sqrt_1mac, int64_t T, void* x_start, void* h, int64_t ldh,
+                           int64_t rows, int64_t dim, double sqrt_c, double horizon, double prior, void* stream);
 /* tran_direction :154-163, in place: noise[i] *= signs[labels[i]] */
 int hd_tran_direction(void* noise, int noise_dtype, const int32_t* labels, const float* signs, int64_t n_centres,
                       int64_t rows, int64_t dim, void* stream);

@@ -107,6 +107,34 @@ def test_hip_diffusion_training_grads(golden):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("noise_dtype", [torch.float64, torch.float32])
+def test_hip_fused_training_prepass_same_bits(noise_dtype):
+    """hd_q_sample_pack_train (normalization + q_sample + the mlp's input concat in one launch) against the three
+    launches it replaces: loss, every gradient and the in-place sign flip of the caller's noise are bit-identical."""
+    from hypdiff_amd.models.direction_diffusion import diffusion
+    rs = np.random.RandomState(11)
+    n, dim, k = 777, 64, 3
+    d = diffusion(types.SimpleNamespace(r=2.0, t=1.0), dim, num_timesteps=200).train()
+    emb = rs.standard_normal((n, dim)).astype(np.float32)
+    emb *= 0.5 / np.linalg.norm(emb, axis=1, keepdims=True)
+    labels = rs.randint(0, k, size=n)
+    u0 = torch.from_numpy((rs.standard_normal((k, dim)) * 0.05).astype(np.float32)).cuda()
+    t = torch.from_numpy(rs.randint(0, 200, size=n)).cuda()
+    noise0 = torch.from_numpy(rs.standard_normal((n, dim))).to(noise_dtype)
+    res = []
+    for fuse in (True, False):
+        d.fuse_prepass = fuse
+        d.mlp.zero_grad(set_to_none=True)
+        noise = noise0.clone().cuda()
+        loss = d(torch.from_numpy(emb).cuda(), None, labels, u0, restrict=True, graphset=True, t=t, noise=noise)
+        loss.backward()
+        res.append((loss.detach().clone(), noise.clone(), [p.grad.clone() for p in d.mlp.parameters()]))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1]) and not torch.equal(res[0][1].cpu(), noise0)
+    assert all(torch.equal(a, b) for a, b in zip(res[0][2], res[1][2]))
+
+
+@pytest.mark.gpu
 def test_hip_ddpm_training_grads(golden):
     from hypdiff_amd.ddpm import Model
     g, gd = golden("train"), golden("ddpm")
