@@ -45,6 +45,7 @@ _agg = [P, P, P, P, P, I64, I64, HdCurv, HdCurv, c_int, c_int, P, I64, P]
 SIZE_QUERIES = {
     "hd_moments_workspace_doubles": [],
     "hd_gemm_tn_workspace_floats": [I64, I64, I64],
+    "hd_gemm_splitk_workspace_floats": [I64, I64, I64],
     "hd_gemm_tn_bf16x3_workspace_floats": [I64, I64, I64],
     "hd_colsum_workspace_floats": [I64, I64],
     "hd_mse_workspace_doubles": [],
@@ -99,6 +100,7 @@ SIGNATURES = {
     "hd_gemm_f64": [P, P, P, P, I64, I64, I64, I64, I64, I64, P],
     "hd_gemm_f32_ex": [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, c_int, P],
     "hd_gemm_f32_bf16x3": [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, c_int, P],
+    "hd_gemm_f32_bf16x3_splitk": [P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, c_int, P, P],
     "hd_limb_pack_f32": [P, I64, I64, I64, P, P],
     "hd_limb_pack_multi_f32": [POINTER(HdPackJob), c_int, P],
     "hd_limb_unpack_f32": [P, I64, I64, P, I64, P],
@@ -134,6 +136,7 @@ SIGNATURES = {
     "hd_ddpm_noise": [P, P, P, P, I64, P, I64, I64, c_int, c_double, c_double, c_double, P],
     "hd_ddpm_step": [P, P, P, c_double, c_double, c_double, P, I64, P],
     "hd_embedding_add": [P, P, P, I64, I64, I64, P],
+    "hd_embedding_grad_f32": [P, P, P, I64, I64, I64, P, P],
     "hd_generate_adj_f32": [P, P, P, I64, I64, P],
     "hd_hkm_to_hyperboloid": [P, P, I64, I64, P],
     "hd_hkm_mean_step": [P, P, P, I64, I64, I64, c_double, P, P],

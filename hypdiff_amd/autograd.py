@@ -45,8 +45,16 @@ def gemm_ex(a, w, bias, resid, aux, c, c2, epi):
     if ev is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.call(ops.gemm_symbol(), ops._p(a), ops._p(w), ops._p(bias), ops._p(resid), ops._p(aux), ops._p(c), ops._p(c2),
-              M, N, a.shape[1], a.stride(0), w.stride(0), ref.stride(0), epi, ops._stream())
+    sym = ops.gemm_symbol()
+    nws = _lib.load().hd_gemm_splitk_workspace_floats(M, N, a.shape[1]) if sym == "hd_gemm_f32_bf16x3" else 0
+    if nws > 0:
+        # few tiles, long K (the 200-row batches of the graph-level DDPM): the K range is split over workgroups
+        ws = _ws(nws, torch.float32, a.device)
+        _lib.call(sym + "_splitk", ops._p(a), ops._p(w), ops._p(bias), ops._p(resid), ops._p(aux), ops._p(c), ops._p(c2),
+                  M, N, a.shape[1], a.stride(0), w.stride(0), ref.stride(0), epi, ops._p(ws), ops._stream())
+    else:
+        _lib.call(sym, ops._p(a), ops._p(w), ops._p(bias), ops._p(resid), ops._p(aux), ops._p(c), ops._p(c2),
+                  M, N, a.shape[1], a.stride(0), w.stride(0), ref.stride(0), epi, ops._stream())
     if ev is not None:
         e1.record()
         ev.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N),
@@ -348,8 +356,8 @@ def linear_stack(x, layers, kinds):
 
 class EmbeddingAdd(torch.autograd.Function):
     """h + table[idx] (ddpm.py:39-41).  Backward: the table gradient is a segment sum of the
-    rows of dL/dh grouped by idx -- an SpMM with the (T x rows) 0/1 selection matrix in CSR
-    (hd_spmm_csr: rows summed in index order, deterministic, no atomics)."""
+    rows of dL/dh grouped by idx (hd_embedding_grad_f32: a device sort, then every table row sums its run in
+    ascending row order -- deterministic, no atomics, nothing read back to the host)."""
 
     @staticmethod
     def forward(ctx, h, table, idx):
@@ -370,10 +378,10 @@ class EmbeddingAdd(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         g = g.contiguous()
         order = torch.sort(idx, stable=True)
-        coo = torch.stack([order.values, order.indices])
-        csr = ops.csr_from_coo(coo, torch.ones(idx.shape[0], dtype=torch.float32, device=g.device),
-                               (ctx.T, idx.shape[0]))
-        return g, ops.spmm(csr, g), None
+        gt = torch.empty(ctx.T, g.shape[1], dtype=torch.float32, device=g.device)
+        _lib.call("hd_embedding_grad_f32", ops._p(g), ops._p(order.values), ops._p(order.indices.contiguous()), g.shape[0],
+                  g.shape[1], ctx.T, ops._p(gt), ops._stream())
+        return g, gt, None
 
 
 class MSELoss(torch.autograd.Function):

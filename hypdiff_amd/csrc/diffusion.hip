@@ -318,6 +318,27 @@ __global__ __launch_bounds__(256) void embedding_add_k(float* __restrict__ h, co
     }
 }
 
+// gradient of the embedding table of embedding_add (autograd of ddpm.py:39-41): out[t] = sum of the rows of g whose
+// index is t, in ascending row order (deterministic, no atomics).  `sorted_idx` / `sorted_rows` = a stable sort of idx
+// (values and positions): table row t owns one contiguous run, found by two binary searches -- nothing is read back to
+// the host, so the step can be captured in a HIP graph.  One workgroup per table row, a thread per column.
+__global__ __launch_bounds__(256) void embedding_grad_k(const float* __restrict__ g, const int64_t* __restrict__ sorted_idx,
+                                                        const int64_t* __restrict__ sorted_rows, int64_t rows, int64_t dim,
+                                                        float* __restrict__ out) {
+    const int64_t t = blockIdx.x;
+    int64_t lo = 0, hi = rows;                       // first position with sorted_idx >= t
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (sorted_idx[mid] < t) lo = mid + 1; else hi = mid; }
+    const int64_t begin = lo;
+    hi = rows;                                       // first position with sorted_idx > t
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (sorted_idx[mid] <= t) lo = mid + 1; else hi = mid; }
+    const int64_t end = lo;
+    for (int64_t c = threadIdx.x; c < dim; c += 256) {
+        float acc = 0.f;
+        for (int64_t k = begin; k < end; ++k) acc += g[sorted_rows[k] * dim + c];
+        out[t * dim + c] = acc;
+    }
+}
+
 inline int ew_grid(int64_t total) {
     int64_t b = (total + 255) / 256;
     if (b < 1) b = 1;
@@ -449,6 +470,14 @@ extern "C" int hd_embedding_add(float* h, const float* table, const int64_t* idx
     HD_REQUIRE(h && table && idx, "hd_embedding_add: null pointer");
     embedding_add_k<<<ew_grid(rows * dim), 256, 0, (hipStream_t)st>>>(h, table, idx, T, rows, dim);
     return check_launch("hd_embedding_add");
+}
+
+extern "C" int hd_embedding_grad_f32(const float* g, const int64_t* sorted_idx, const int64_t* sorted_rows, int64_t rows,
+                                     int64_t dim, int64_t T, float* out, void* st) {
+    HD_REQUIRE(rows >= 0 && dim >= 1 && T >= 1 && T < (1LL << 31), "hd_embedding_grad_f32: bad shape");
+    HD_REQUIRE(out && (rows == 0 || (g && sorted_idx && sorted_rows)), "hd_embedding_grad_f32: null pointer");
+    embedding_grad_k<<<dim3((unsigned)T), 256, 0, (hipStream_t)st>>>(g, sorted_idx, sorted_rows, rows, dim, out);
+    return check_launch("hd_embedding_grad_f32");
 }
 
 extern "C" int64_t hd_moments_workspace_doubles(void) { return 2 * kMomentBlocks; }

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void gemm_f32_bf16x3(const float* __restrict__
                                                        const float* __restrict__ aux, float* __restrict__ C,
                                                        float* __restrict__ C2,
                                                        int M, int N, int K, int lda, int ldw, int ldc, int epi,
-                                                       int tiles_m, int tiles_n) {
+                                                       int tiles_m, int tiles_n, int kps, float* __restrict__ partial) {
     constexpr int NT = BNT / 64;               // 32-col MFMA tiles per wavefront along N
     __shared__ __attribute__((aligned(16))) unsigned short sA[3][BM * PB];
     __shared__ __attribute__((aligned(16))) unsigned short sW[3][BNT * PB];
@@ -170,10 +170,14 @@ __global__ __launch_bounds__(256) void gemm_f32_bf16x3(const float* __restrict__
     const int fi = lane & 31, fh = lane >> 5;
     // a wavefront whose quadrant lies entirely beyond M or N only stages (see gemm.hip)
     const bool wave_live = (m0 + wr * 64 < M) && (n0 + wc * (BNT / 2) < N);
-    const int nk = (K + BK - 1) / BK;
-    HD_GLOAD(0)
+    // split-K (partial != nullptr): workgroup (tile, z = blockIdx.y) multiplies slabs [z kps, (z + 1) kps) only and stores
+    // the raw accumulators in partial[z]; splitk_epilogue adds the splits in order and applies bias / epilogue
+    const int nk_all = (K + BK - 1) / BK;
+    const int kt0 = partial ? (int)blockIdx.y * kps : 0;
+    const int nk = partial ? (kt0 + kps < nk_all ? kt0 + kps : nk_all) : nk_all;
+    HD_GLOAD(kt0 * BK)
     if (!wave_live) {
-        for (int kt = 0; kt < nk; ++kt) {
+        for (int kt = kt0; kt < nk; ++kt) {
             HD_SSTORE()
             __syncthreads();
             HD_GLOAD((kt + 1) * BK)
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(256) void gemm_f32_bf16x3(const float* __restrict__
         }
         return;
     }
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk; ++kt) {
         HD_SSTORE()
         __syncthreads();
         HD_GLOAD((kt + 1) * BK)                    // past the end: clamped re-read, never stored
@@ -200,6 +204,15 @@ __global__ __launch_bounds__(256) void gemm_f32_bf16x3(const float* __restrict__
         for (int j = 0; j < NT; ++j) {
             const int cn = n0 + wc * (BNT / 2) + j * 32 + fi;
             if (cn >= N) continue;
+            if (partial) {
+                float* po = partial + (size_t)blockIdx.y * M * N;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rm = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    if (rm < M) po[(size_t)rm * N + cn] = acc[i][j][r];
+                }
+                continue;
+            }
             const float bv = bias ? bias[cn] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -222,11 +235,52 @@ __global__ __launch_bounds__(256) void gemm_f32_bf16x3(const float* __restrict__
         }
 }
 
+// sum of the split-K partials in split order, then the write-out of gemm_f32_bf16x3 (same expressions)
+__global__ __launch_bounds__(256) void splitk_epilogue(const float* __restrict__ partial, int splits,
+                                                       const float* __restrict__ bias, const float* __restrict__ resid,
+                                                       const float* __restrict__ aux, float* __restrict__ C,
+                                                       float* __restrict__ C2, int M, int N, int ldc, int epi) {
+    const size_t total = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int rm = (int)(i / N), cn = (int)(i - (size_t)rm * N);
+        float a = partial[i];
+        for (int z = 1; z < splits; ++z) a += partial[(size_t)z * total + i];
+        const size_t o = (size_t)rm * ldc + cn;
+        float v = a + (bias ? bias[cn] : 0.f);
+        if (epi == 3) {
+            if (resid) v += resid[o];
+            if (C) C[o] = v;
+            if (C2) C2[o] = v * gelu_erf_grad(aux[o]);
+        } else {
+            if (epi != 0 && C2) C2[o] = v;
+            if (epi == 1) v = gelu_erf(v);
+            else if (epi == 2) v = resid[o] + gelu_erf(v);
+            C[o] = v;
+        }
+    }
+}
+
+// split-K only pays where the tiles alone leave most of the chip idle (the graph-level DDPM's 200-row batches:
+// 200 x 512 x 512 is 16 tiles of 16 slabs, 57 us of exposed load latency on 16 CUs)
+inline int splitk_splits(int64_t M, int64_t N, int64_t K) {
+    const int64_t tiles = ((M + BM - 1) / BM) * ((N + 63) / 64), nk = (K + BK - 1) / BK;
+    if (tiles >= 64 || nk < 4) return 1;
+    int64_t s = 256 / tiles;
+    s = s < nk / 2 ? s : nk / 2;
+    return (int)(s < 1 ? 1 : (s > 16 ? 16 : s));
+}
+
 }  // namespace
 
-extern "C" int hd_gemm_f32_bf16x3(const void* A, const void* W, const void* bias, const void* resid, const void* aux,
-                                  void* C, void* C2, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
-                                  int64_t ldc, int epi, void* st) {
+extern "C" int64_t hd_gemm_splitk_workspace_floats(int64_t M, int64_t N, int64_t K) {
+    if (M < 1 || N < 1 || K < 1) return 0;
+    const int s = splitk_splits(M, N, K);
+    return s > 1 ? (int64_t)s * M * N : 0;
+}
+
+static int gemm_bf16x3_impl(const void* A, const void* W, const void* bias, const void* resid, const void* aux,
+                            void* C, void* C2, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                            int64_t ldc, int epi, void* workspace, void* st) {
     HD_REQUIRE(M >= 0 && N >= 1 && K >= 1, "hd_gemm_f32_bf16x3: bad shape M=%lld N=%lld K=%lld", (long long)M,
                (long long)N, (long long)K);
     if (M == 0) return HD_OK;
@@ -238,6 +292,20 @@ extern "C" int hd_gemm_f32_bf16x3(const void* A, const void* W, const void* bias
     HD_REQUIRE(epi >= 0 && epi <= 3 && (epi != 2 || resid), "hd_gemm_f32_bf16x3: bad epilogue / missing residual");
     HD_REQUIRE(epi != 3 || !C2 || aux, "hd_gemm_f32_bf16x3: gradient epilogue needs the saved pre-activation");
     const int tiles_m = (int)((M + BM - 1) / BM);
+    const int splits = workspace ? splitk_splits(M, N, K) : 1;
+    if (splits > 1) {
+        HD_REQUIRE(is_aligned16(workspace), "hd_gemm_f32_bf16x3_splitk: misaligned workspace");
+        const int nk = (int)((K + BK - 1) / BK), kps = (nk + splits - 1) / splits, zs = (nk + kps - 1) / kps;
+        const int tiles_n = (int)((N + 63) / 64);
+        gemm_f32_bf16x3<64><<<dim3((unsigned)(tiles_m * tiles_n), (unsigned)zs), dim3(256), 0, (hipStream_t)st>>>(
+            (const float*)A, (const float*)W, nullptr, nullptr, nullptr, nullptr, nullptr, (int)M, (int)N, (int)K, (int)lda,
+            (int)ldw, (int)N, 0, tiles_m, tiles_n, kps, (float*)workspace);
+        int blocks = (int)(((size_t)M * N + 255) / 256);
+        blocks = blocks < 2048 ? blocks : 2048;
+        splitk_epilogue<<<blocks, 256, 0, (hipStream_t)st>>>((const float*)workspace, zs, (const float*)bias, (const float*)resid,
+                                                             (const float*)aux, (float*)C, (float*)C2, (int)M, (int)N, (int)ldc, epi);
+        return check_launch("hd_gemm_f32_bf16x3_splitk");
+    }
     int width = 128;
     if (const char* e = getenv("HD_GEMM_SPLIT_TUNE")) {      // tuning hook: "n" = 128x64 tile, "w" = 128x128
         if (e[0] == 'n') width = 64; else if (e[0] == 'w') width = 128;
@@ -246,12 +314,24 @@ extern "C" int hd_gemm_f32_bf16x3(const void* A, const void* W, const void* bias
         const int tiles_n = (int)((N + 63) / 64);
         gemm_f32_bf16x3<64><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, (hipStream_t)st>>>(
             (const float*)A, (const float*)W, (const float*)bias, (const float*)resid, (const float*)aux, (float*)C,
-            (float*)C2, (int)M, (int)N, (int)K, (int)lda, (int)ldw, (int)ldc, epi, tiles_m, tiles_n);
+            (float*)C2, (int)M, (int)N, (int)K, (int)lda, (int)ldw, (int)ldc, epi, tiles_m, tiles_n, 0, nullptr);
     } else {
         const int tiles_n = (int)((N + 127) / 128);
         gemm_f32_bf16x3<128><<<dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, (hipStream_t)st>>>(
             (const float*)A, (const float*)W, (const float*)bias, (const float*)resid, (const float*)aux, (float*)C,
-            (float*)C2, (int)M, (int)N, (int)K, (int)lda, (int)ldw, (int)ldc, epi, tiles_m, tiles_n);
+            (float*)C2, (int)M, (int)N, (int)K, (int)lda, (int)ldw, (int)ldc, epi, tiles_m, tiles_n, 0, nullptr);
     }
     return check_launch("hd_gemm_f32_bf16x3");
+}
+
+extern "C" int hd_gemm_f32_bf16x3(const void* A, const void* W, const void* bias, const void* resid, const void* aux,
+                                  void* C, void* C2, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                                  int64_t ldc, int epi, void* st) {
+    return gemm_bf16x3_impl(A, W, bias, resid, aux, C, C2, M, N, K, lda, ldw, ldc, epi, nullptr, st);
+}
+
+extern "C" int hd_gemm_f32_bf16x3_splitk(const void* A, const void* W, const void* bias, const void* resid, const void* aux,
+                                         void* C, void* C2, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw,
+                                         int64_t ldc, int epi, void* workspace, void* st) {
+    return gemm_bf16x3_impl(A, W, bias, resid, aux, C, C2, M, N, K, lda, ldw, ldc, epi, workspace, st);
 }

@@ -29,9 +29,10 @@ inline int tn_target_wgs() {
 }
 
 inline int host_slices(int64_t R, int64_t tiles) {
-    // one resident round: 256 CUs x 2 workgroups (212 VGPRs, 48 KB LDS); slices of at least 8 slabs
+    // one resident round: 256 CUs x 2 workgroups (212 VGPRs, 48 KB LDS); slices of at least 2 slabs (a 200-row batch
+    // is 7 slabs: four slices instead of one workgroup per tile)
     int64_t s = tn_target_wgs() / tiles;
-    const int64_t max_s = (R + 8 * TR - 1) / (8 * TR);
+    const int64_t max_s = (R + 2 * TR - 1) / (2 * TR);
     s = s < 1 ? 1 : (s > max_s ? max_s : s);
     return (int)(s > 64 ? 64 : s);
 }

@@ -248,6 +248,14 @@ int hd_gemm_f32_ex(const void* A, const void* W, const void* bias, const void* r
 int hd_gemm_f32_bf16x3(const void* A, const void* W, const void* bias, const void* resid, const void* aux, void* C,
                        void* C2, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int epi,
                        void* stream);
+/* The same product with the K range split over workgroups where the tiles alone would leave the chip idle (the
+ * graph-level DDPM's 200-row batches, ddpm.py:9-41): partial tiles in `workspace`
+ * (hd_gemm_splitk_workspace_floats(M,N,K) floats; 0 = no split pays, workspace may be NULL), summed in split order, then
+ * the same bias / epilogue.  Bit-reproducible; differs from the unsplit kernel only in the order of the fp32 sums. */
+int64_t hd_gemm_splitk_workspace_floats(int64_t M, int64_t N, int64_t K);
+int hd_gemm_f32_bf16x3_splitk(const void* A, const void* W, const void* bias, const void* resid, const void* aux, void* C,
+                              void* C2, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldw, int64_t ldc, int epi,
+                              void* workspace, void* stream);
 /* ---- the same contraction with operands pre-split into bf16 limbs ("limb images") ----
  * Limb image of a (rows, cols) fp32 matrix: 16-byte chunks of 8 bf16,
  *   chunk(rb, s, l, kc, r) = (((rb*nslab + s)*3 + l)*4 + kc)*128 + r,
@@ -464,6 +472,11 @@ int hd_ddpm_step(const float* x, const float* eps, const float* noise, double c1
 /* Backbone.forward ddpm.py:39-41: h[r] += table[idx[r]] in place */
 int hd_embedding_add(float* h, const float* table, const int64_t* idx, int64_t T, int64_t rows, int64_t dim,
                      void* stream);
+/* Its table gradient (autograd of ddpm.py:39-41): out[t] (T, dim) = sum of the rows r of g (rows, dim) with idx[r] == t,
+ * in ascending r.  sorted_idx / sorted_rows = the values and positions of a stable ascending sort of idx (indices outside
+ * [0, T) contribute nothing).  No read-back: usable under HIP graph capture. */
+int hd_embedding_grad_f32(const float* g, const int64_t* sorted_idx, const int64_t* sorted_rows, int64_t rows, int64_t dim,
+                          int64_t T, float* out, void* stream);
 
 /* ---- latent -> graph decoding, diff.py:327-378 --------------------------------------------------
  * The tensor part of generate (:334-349) and decode_adj (:355-378) for a set of graphs: h (n_graphs, n, n) fp32

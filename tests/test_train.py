@@ -480,6 +480,36 @@ def test_hip_limb_pack_multi_matches_single():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(200, 512, 512), (37, 64, 512), (513, 96, 260)])
+def test_hip_gemm_splitk_epilogues(M, N, K):
+    """hd_gemm_f32_bf16x3_splitk (few tiles, long K: the graph-level DDPM's batches) under every epilogue against fp64:
+    forward none / GELU / residual + GELU with the pre-activation copy, and the input-gradient form."""
+    from hypdiff_amd import _lib, autograd as hag
+    from scipy.special import erf
+    assert _lib.load().hd_gemm_splitk_workspace_floats(M, N, K) > 0
+    rs = np.random.RandomState(M + N + K)
+    a, w = rs.standard_normal((M, K)).astype(np.float32), (rs.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b, r, z = (rs.standard_normal(sh).astype(np.float32) for sh in ((N,), (M, N), (M, N)))
+    ad, wd, bd, rd, zd = (torch.from_numpy(v).cuda() for v in (a, w, b, r, z))
+    lin = a.astype(np.float64) @ w.astype(np.float64).T
+    bound = 2e-6 * (np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64).T) + 1e-6
+    gelu = lambda v: 0.5 * v * (1.0 + erf(v / np.sqrt(2.0)))
+    dgelu = lambda v: 0.5 * (1.0 + erf(v / np.sqrt(2.0))) + v * np.exp(-0.5 * v * v) / np.sqrt(2.0 * np.pi)
+    for epi in (0, 1, 2):
+        c, c2 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+        hag.gemm_ex(ad, wd, bd, rd if epi == 2 else None, None, c, c2 if epi else None, epi)
+        pre = lin + b
+        want = pre if epi == 0 else (gelu(pre) if epi == 1 else r + gelu(pre))
+        assert (np.abs(c.cpu().numpy() - want) <= 2.0 * bound).all(), epi
+        if epi:
+            assert (np.abs(c2.cpu().numpy() - pre) <= bound).all(), epi
+    g, dzb = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    hag.gemm_ex(ad, wd, None, rd, zd, g, dzb, 3)
+    assert (np.abs(g.cpu().numpy() - (lin + r)) <= bound).all()
+    assert (np.abs(dzb.cpu().numpy() - (lin + r) * dgelu(z.astype(np.float64))) <= 2.0 * bound).all()
+
+
+@pytest.mark.gpu
 def test_hip_dgrad_epilogue_transpose_colsum():
     from hypdiff_amd import autograd as hag
     rs = np.random.RandomState(2)
