@@ -117,7 +117,7 @@ SIGNATURES = {
     "hd_gemm_tn_bf16x3_f32": [P, P, P, P, I64, I64, I64, I64, I64, I64, P, P],
     "hd_gemm_tn_limbs_f32": [P, P, P, P, I64, I64, I64, I64, P, P],
     "hd_transpose_f32": [P, P, I64, I64, I64, I64, P],
-    "hd_adam_step_f32": [POINTER(HdAdamJob), c_int, P, P, P, c_double, c_double, c_double, c_double, I64, P],
+    "hd_adam_step_f32": [POINTER(HdAdamJob), c_int, P, P, P, c_double, c_double, c_double, c_double, I64, P, P],
     "hd_colsum_f32": [P, P, I64, I64, I64, P, P],
     "hd_bias_gelu_f32": [P, P, P, P, I64, I64, c_int, P],
     "hd_gelu_bwd_f32": [P, P, P, I64, P],

@@ -396,16 +396,29 @@ extern "C" int hd_gelu_bwd_f32(const void* g, const void* z, void* dz, int64_t c
 // 2.8 M parameters; this is one pass over p, g, m, v at HBM speed).  Arithmetic in the order of torch.optim.Adam's
 // default path: m += (g - m)(1 - b1); v = v b2 + (1 - b2) g g; p += -(lr / (1 - b1^t)) * (m / (sqrt(v) / sqrt(1 - b2^t) + eps)).
 namespace {
-constexpr int kMaxAdamJobs = 32;
+constexpr int kMaxAdamJobs = 128;
 struct AdamJobs {
     int n;
     float* p[kMaxAdamJobs];
     unsigned off[kMaxAdamJobs], count[kMaxAdamJobs], block0[kMaxAdamJobs];
 };
 
+// step counter on the device (a captured HIP graph replays the same kernel arguments): state = {t, -lr / (1 - b1^t),
+// sqrt(1 - b2^t)} as doubles; one thread advances it ahead of adam_multi on the same stream
+__global__ void adam_tick(double* __restrict__ state, double lr, double beta1, double beta2) {
+    const double t = state[0] + 1.0;
+    state[0] = t;
+    state[1] = -(lr / (1.0 - pow(beta1, t)));
+    state[2] = sqrt(1.0 - pow(beta2, t));
+}
+
 __global__ __launch_bounds__(256) void adam_multi(const AdamJobs jobs, const float* __restrict__ g, float* __restrict__ m,
                                                   float* __restrict__ v, float w1, float b2, float w2, float neg_step,
-                                                  float bc2_sqrt, float eps) {
+                                                  float bc2_sqrt, float eps, const double* __restrict__ state) {
+    if (state) {
+        neg_step = (float)state[1];
+        bc2_sqrt = (float)state[2];
+    }
     int k = 0;
     while (k + 1 < jobs.n && blockIdx.x >= jobs.block0[k + 1]) ++k;
     float* __restrict__ p = jobs.p[k];
@@ -428,10 +441,10 @@ __global__ __launch_bounds__(256) void adam_multi(const AdamJobs jobs, const flo
 
 extern "C" int hd_adam_step_f32(const hd_adam_job* jobs, int n_jobs, const void* grad_flat, void* exp_avg_flat,
                                 void* exp_avg_sq_flat, double lr, double beta1, double beta2, double eps, int64_t step,
-                                void* st) {
+                                void* step_state, void* st) {
     HD_REQUIRE(n_jobs >= 0 && n_jobs <= kMaxAdamJobs && (jobs || n_jobs == 0), "hd_adam_step_f32: between 0 and %d jobs per call",
                kMaxAdamJobs);
-    HD_REQUIRE(step >= 1 && lr >= 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0,
+    HD_REQUIRE((step >= 1 || step_state) && lr >= 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0,
                "hd_adam_step_f32: bad hyper-parameters (step counts from 1)");
     AdamJobs aj;
     aj.n = 0;
@@ -450,9 +463,12 @@ extern "C" int hd_adam_step_f32(const hd_adam_job* jobs, int n_jobs, const void*
     if (aj.n == 0) return HD_OK;
     HD_REQUIRE(grad_flat && exp_avg_flat && exp_avg_sq_flat, "hd_adam_step_f32: null pointer");
     HD_REQUIRE(blocks < (1ULL << 31), "hd_adam_step_f32: too many workgroups");
-    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    // step_state: the count lives on the device; step > 0 there means "advance it now" (the first group of jobs of a step)
+    if (step_state && step > 0) adam_tick<<<1, 1, 0, (hipStream_t)st>>>((double*)step_state, lr, beta1, beta2);
+    const double tt = step >= 1 ? (double)step : 1.0;
+    const double bc1 = 1.0 - pow(beta1, tt), bc2 = 1.0 - pow(beta2, tt);
     adam_multi<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)st>>>(
         aj, (const float*)grad_flat, (float*)exp_avg_flat, (float*)exp_avg_sq_flat, (float)(1.0 - beta1), (float)beta2,
-        (float)(1.0 - beta2), (float)(-(lr / bc1)), (float)sqrt(bc2), (float)eps);
+        (float)(1.0 - beta2), (float)(-(lr / bc1)), (float)sqrt(bc2), (float)eps, (const double*)step_state);
     return check_launch("hd_adam_step_f32");
 }

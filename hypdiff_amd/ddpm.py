@@ -112,7 +112,12 @@ class Model(nn.Module):
         ops._dev(x)
         if idx is None or _train:
             if idx is None:
-                idx = torch.randint(0, len(self.alpha_bars), (x.size(0),)).to(x.device)
+                if x.is_cuda and torch.cuda.is_current_stream_capturing():
+                    # under HIP graph capture the draw has to happen on the device (the reference draws on the host
+                    # and copies, ddpm.py:93: same distribution, another generator)
+                    idx = torch.randint(0, len(self.alpha_bars), (x.size(0),), device=x.device)
+                else:
+                    idx = torch.randint(0, len(self.alpha_bars), (x.size(0),)).to(x.device)
             idx = idx.to(device=x.device, dtype=torch.int64).contiguous()
             ab = self._alpha_bars_dev(x.device)
             used_alpha_bars = ab[idx][:, None]

@@ -370,13 +370,16 @@ int hd_gemm_tn_bf16x3_f32(const void* A, const void* B, void* C, void* colsum_a,
 /* optimizer.step() of optim.Adam(diff.parameters(), lr) (diff.py:107,117; diff_graphset.py:66,74; torch defaults: no weight
  * decay, no amsgrad) for every parameter tensor in ONE launch: job i updates `count` fp32 elements at `param` from the
  * gradient / first / second moment elements [offset, offset + count) of three flat fp32 arrays (the gradient bucket of
- * the data-parallel trainer and two state arrays of the same layout).  `step` counts from 1.  At most 32 jobs. */
+ * the data-parallel trainer and two state arrays of the same layout).  `step` counts from 1.  At most 128 jobs.
+ * step_state (3 doubles on the device, zero-filled once, or NULL): the step count lives there instead -- a call with
+ * step > 0 advances it by one before the update, a call with step <= 0 (further job groups of the same step) uses it
+ * as it is -- so that a HIP graph holding this call replays with the right bias corrections. */
 typedef struct hd_adam_job {
     void* param;
     int64_t offset, count;
 } hd_adam_job;
 int hd_adam_step_f32(const hd_adam_job* jobs, int n_jobs, const void* grad_flat, void* exp_avg_flat, void* exp_avg_sq_flat,
-                     double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
+                     double lr, double beta1, double beta2, double eps, int64_t step, void* step_state, void* stream);
 /* The same weight gradient (and bias gradient) from bf16x3 limb IMAGES of A (R x P) and B (R x Q) -- the images the
  * forward and input-gradient launches of hd_gemm_limbs_train_f32 write anyway, so training keeps no fp32 copies of dz or
  * of the layer inputs.  The contraction runs over image rows (LDS-DMA + ds_read_b64_tr_b16 transposing reads); the pad

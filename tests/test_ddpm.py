@@ -173,3 +173,33 @@ def test_linear_chain_small_shapes():
     assert ops._lib.load().hd_chain_failed(ops._p(wsb), ops._stream()) == 0
     with pytest.raises(RuntimeError, match="rows must be"):
         ops._lib.call("hd_linear_chain_small_f32", None, 64, 513, None, 1, None, None, 0, None, 64, None, 0, ops._stream())
+
+
+@pytest.mark.gpu
+def test_graphed_train_step_equals_eager():
+    """DataParallelTrainer.capture: the whole ddpm.Model training step (loss, backward, one-launch Adam with its step
+    count on the device) as one HIP graph.  3 warm-up steps + 2 replays leave exactly the parameters of 5 eager steps;
+    versions are bumped per replay; with the draws left to the model, replays see fresh device random numbers."""
+    import copy
+    from hypdiff_amd.ddpm import Model
+    from hypdiff_amd.dist import DataParallelTrainer
+    torch.manual_seed(3)
+    B, D = 200, 64
+    m1 = Model(D, 128, 3, 100, 1e-4, 0.02).cuda().train()
+    m2 = copy.deepcopy(m1)
+    x = torch.randn(B, D, device="cuda")
+    idx = torch.randint(0, 100, (B,), device="cuda")
+    eps = torch.randn(B, D, device="cuda")
+    t1, t2 = DataParallelTrainer(m1, lr=1e-3), DataParallelTrainer(m2, lr=1e-3)
+    eager = [float(t1.step(lambda: m1.loss_fn(x, idx=idx, epsilon=eps))) for _ in range(5)]
+    replay = t2.capture(lambda: m2.loss_fn(x, idx=idx, epsilon=eps), warmup=3)
+    v0 = [p._version for p in m2.parameters()]
+    graphed = [float(replay()) for _ in range(2)]
+    assert graphed == eager[3:], (graphed, eager)
+    assert all(torch.equal(a, b) for a, b in zip(m1.parameters(), m2.parameters()))
+    assert all(p._version > v for p, v in zip(m2.parameters(), v0))
+    assert eager[4] < eager[0]
+    # draws inside the graph: every replay noises the batch afresh
+    replay2 = t2.capture(lambda: m2.loss_fn(x), warmup=1)
+    ls = [float(replay2()) for _ in range(4)]
+    assert len(set(ls)) == 4 and all(np.isfinite(ls))

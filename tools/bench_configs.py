@@ -84,6 +84,9 @@ def config3():
     tr = DataParallelTrainer(model, lr=1e-3)
     out("3: BA graph-set latent DDPM", "ddpm.Model train step fwd+bwd+Adam (latent-steps/s)", B,
         timeit(lambda: tr.step(lambda: model.loss_fn(x)), 20), rows=B, hidden=Hd)
+    replay = tr.capture(lambda: model.loss_fn(x))
+    out("3: BA graph-set latent DDPM", "ddpm.Model train step fwd+bwd+Adam as ONE HIP graph (latent-steps/s)", B,
+        timeit(replay, 50), rows=B, hidden=Hd)
     for Bb in (4096, 32768):
         xb = torch.randn(Bb, D, device=dev)
         out("3: BA graph-set latent DDPM", "ddpm.Model train step fwd+bwd+Adam (latent-steps/s)", Bb,
