@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""25 eager training steps of ddpm.Model at config 3's shape (for rocprofv3 --kernel-trace --stats): B=200 tools/prof_train_c3.py"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hypdiff_amd.ddpm import Model
