@@ -69,6 +69,13 @@ def graph_set(manifold, c, n_graphs, total_nodes, total_edges, n_min, n_max, fea
     tr = DataParallelTrainer(diff.mlp, lr=1e-3)
     out(tag, "denoiser train step fwd+bwd+Adam (node-steps/s)", n,
         timeit(lambda: tr.step(lambda: diff(emb, None, labels, u0, restrict=True, graphset=True)), 15), rows=n, dim=dim)
+    try:
+        if os.environ.get("HD_BENCH_NO_GRAPH"):
+            raise RuntimeError("skipped (HD_BENCH_NO_GRAPH)")
+        replay = tr.capture(lambda: diff(emb, None, labels, u0, restrict=True, graphset=True))
+        out(tag, "denoiser train step fwd+bwd+Adam as ONE HIP graph (node-steps/s)", n, timeit(replay, 30), rows=n, dim=dim)
+    except Exception as e:                                   # report, keep the other lines
+        print(json.dumps(dict(config=tag, what="graphed train step", error=repr(e)[:300])), flush=True)
 
 
 def config3():
@@ -91,6 +98,17 @@ def config3():
         xb = torch.randn(Bb, D, device=dev)
         out("3: BA graph-set latent DDPM", "ddpm.Model train step fwd+bwd+Adam (latent-steps/s)", Bb,
             timeit(lambda: tr.step(lambda: model.loss_fn(xb)), 10), rows=Bb, hidden=Hd)
+
+
+def config3_again():
+    B, D, Hd, L, T = 200, 64, 512, 10, 1000
+    model = Model(D, Hd, L, T, 1e-4, 0.02).to(dev).eval()
+    x = torch.randn(B, D, device=dev)
+    s = DDPMSampler(1e-4, 0.02, T, model, dev, (D,))
+    with torch.no_grad():
+        nz = torch.randn_like(x)
+        out("3: BA graph-set latent DDPM", "DDPMSampler step again, at the end of this process (after the captured steps)", B,
+            timeit(lambda: s.one_step(x, 500, nz), 50), rows=B, hidden=Hd)
 
 
 def config4():
@@ -132,7 +150,11 @@ def config4():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
+    # config 3 first: its one-launch (cooperative) sampler step measured 0.32 ms instead of 0.19 when the process's FIRST
+    # cooperative launch came after the captured mlp steps of configs 1 / 2; once it has run early, it stays at 0.19
+    # after them too (config3_again() records that).  Not reproduced in four isolation scripts; cause open.
+    config3()
     graph_set("PoincareBall", 1.0, 1000, 7850, 4684, 2, 14, 14, 14, 200, "1: SynCommunity1000-shaped (sum N=7850), PoincareBall, D=14, T=200")
     graph_set("Hyperboloid", 1.0, 1197, 15777, 16608, 4, 20, 20, 512, 1000, "2: SynEgo1000-shaped (sum N=15777), Hyperboloid, D=512, T=1000")
-    config3()
     config4()
+    config3_again()
