@@ -557,7 +557,7 @@ class HypAggFn(torch.autograd.Function):
 class EdgeDecodeFn(torch.autograd.Function):
     """LPModel.decode (models/base_models.py:152-159): gather both endpoints, sqdist and the
     Fermi-Dirac map in one kernel; backward = one VJP kernel writing the two endpoint
-    gradients of every pair, summed per node by a selection-matrix SpMM (no atomics)."""
+    gradients of every pair, summed per node in pair order by hd_embedding_grad_f32 (no atomics, no read-back)."""
 
     @staticmethod
     def forward(ctx, h, idx, abi, cv, r, t):
@@ -579,11 +579,14 @@ class EdgeDecodeFn(torch.autograd.Function):
         ge = torch.empty(2 * E, h.shape[1], dtype=h.dtype, device=h.device)
         _lib.call(f"hd_{abi}_edge_decode_bwd_f32", ops._p(h), ops._p(idx), h.shape[0], ops._p(g), ops._p(ge), E, h.shape[1],
                   cv, 1, r, t, ops._stream())
+        # per-node sum of the 2E endpoint gradients in ascending pair order: a device sort and one segment-sum launch
+        # (the kernel of the embedding-table gradient), nothing read back to the host
         node = torch.cat([idx[:, 0], idx[:, 1]])
         order = torch.sort(node, stable=True)
-        csr = ops.csr_from_coo(torch.stack([order.values, order.indices]),
-                               torch.ones(2 * E, dtype=h.dtype, device=h.device), (h.shape[0], 2 * E))
-        return ops.spmm(csr, ge), None, None, None, None, None
+        gh = torch.empty_like(h)
+        _lib.call("hd_embedding_grad_f32", ops._p(ge), ops._p(order.values), ops._p(order.indices.contiguous()), 2 * E,
+                  h.shape[1], h.shape[0], ops._p(gh), ops._stream())
+        return gh, None, None, None, None, None
 
 
 # ---- gcndec denoiser (models/direction_diffusion.py:17-44) -----------------------------------

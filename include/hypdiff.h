@@ -477,7 +477,8 @@ int hd_embedding_add(float* h, const float* table, const int64_t* idx, int64_t T
                      void* stream);
 /* Its table gradient (autograd of ddpm.py:39-41): out[t] (T, dim) = sum of the rows r of g (rows, dim) with idx[r] == t,
  * in ascending r.  sorted_idx / sorted_rows = the values and positions of a stable ascending sort of idx (indices outside
- * [0, T) contribute nothing).  No read-back: usable under HIP graph capture. */
+ * [0, T) contribute nothing).  No read-back: usable under HIP graph capture.  The same segment sum adds up the endpoint
+ * gradients per node in the backward pass of LPModel.decode (models/base_models.py:152-159). */
 int hd_embedding_grad_f32(const float* g, const int64_t* sorted_idx, const int64_t* sorted_rows, int64_t rows, int64_t dim,
                           int64_t T, float* out, void* stream);
 

@@ -146,6 +146,13 @@ def config4():
         opt.step()
     out(tag, "lp_train epoch: encode + decode + BCE + backward + Adam (nodes/s)", n, timeit(step, 20), rows=n, dim=dim,
         edges=int(tri.shape[0]))
+    try:
+        tr = DataParallelTrainer(lp, lr=1e-4)
+        replay = tr.capture(lambda: lp.lp_loss(lp.encode(feats, adj)[0], pos, neg))
+        out(tag, "lp_train epoch as ONE HIP graph (nodes/s)", n, timeit(replay, 30), rows=n, dim=dim, edges=int(tri.shape[0]))
+    except Exception as e:
+        import traceback
+        print(json.dumps(dict(config=tag, what="graphed lp_train epoch", error=traceback.format_exc()[-700:])), flush=True)
 
 
 if __name__ == "__main__":
