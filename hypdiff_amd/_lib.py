@@ -33,6 +33,12 @@ class HdAdamJob(ctypes.Structure):
     _fields_ = [("param", c_void_p), ("offset", c_int64), ("count", c_int64)]
 
 
+class HdTransposeJob(ctypes.Structure):
+    """struct hd_transpose_job of include/hypdiff.h"""
+    _fields_ = [("inp", c_void_p), ("out", c_void_p), ("rows", c_int64), ("cols", c_int64), ("ld_in", c_int64),
+                ("ld_out", c_int64)]
+
+
 P = c_void_p
 I64 = c_int64
 _map1 = [P, P, I64, I64, HdCurv, P]
@@ -117,6 +123,7 @@ SIGNATURES = {
     "hd_gemm_tn_bf16x3_f32": [P, P, P, P, I64, I64, I64, I64, I64, I64, P, P],
     "hd_gemm_tn_limbs_f32": [P, P, P, P, I64, I64, I64, I64, P, P],
     "hd_transpose_f32": [P, P, I64, I64, I64, I64, P],
+    "hd_transpose_multi_f32": [POINTER(HdTransposeJob), c_int, P],
     "hd_adam_step_f32": [POINTER(HdAdamJob), c_int, P, P, P, c_double, c_double, c_double, c_double, I64, P, P],
     "hd_colsum_f32": [P, P, I64, I64, I64, P, P],
     "hd_bias_gelu_f32": [P, P, P, P, I64, I64, c_int, P],

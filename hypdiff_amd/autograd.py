@@ -151,6 +151,19 @@ def transpose(w):
     return out
 
 
+def transpose_multi(ws):
+    """[w^T for w in ws] in one launch per 64 matrices (hd_transpose_multi_f32)."""
+    outs, jobs = [], []
+    for w in ws:
+        o = torch.empty(w.shape[1], w.shape[0], dtype=torch.float32, device=w.device)
+        outs.append(o)
+        jobs.append(_lib.HdTransposeJob(w.data_ptr(), o.data_ptr(), w.shape[0], w.shape[1], w.stride(0), o.stride(0)))
+    for i in range(0, len(jobs), 64):
+        part = jobs[i:i + 64]
+        _lib.call("hd_transpose_multi_f32", (_lib.HdTransposeJob * len(part))(*part), len(part), ops._stream())
+    return outs
+
+
 def colsum(x, out=None):
     M, N = x.shape
     if out is None:
@@ -277,6 +290,8 @@ class LinearStack(torch.autograd.Function):
             dz, g_up = gy, None
         else:       # stack ending in an activation: dz = gy * gelu'(z) through the same epilogue
             raise NotImplementedError("LinearStack: the last layer must be linear")
+        lo = 0 if ctx.need_x else 1
+        wts = [None] * lo + transpose_multi(ws_[lo:])     # (K_l, N_l): contraction over N_l; every W^T in one launch
         for l in range(top, -1, -1):
             x_l, w = xs[l], ws_[l]
             shp = ctx.wshapes[l]
@@ -296,7 +311,7 @@ class LinearStack(torch.autograd.Function):
                 grads[2 * l] = dw if tuple(dw.shape) == shp else dw[:, :shp[1]].contiguous()
             if l == 0 and not ctx.need_x:
                 break
-            wt = transpose(w)                                    # (K_l, N_l): contraction over N_l
+            wt = wts[l]
             M, Kl = x_l.shape
             resid = g_up if kinds[l] == RES else None
             if l == 0:

@@ -173,6 +173,33 @@ __global__ __launch_bounds__(256) void transpose_f32(const float* __restrict__ i
         if (c0 + c < cols && r0 + tx < rows) out[(size_t)(c0 + c) * ld_out + r0 + tx] = tile[tx][c];
 }
 
+// every W^T of a backward pass in ONE launch (24 weights of the graph-level DDPM: 23 launches of 8 us otherwise)
+constexpr int kMaxTransposeJobs = 64;
+struct TransposeJobs {
+    int n;
+    const float* in[kMaxTransposeJobs];
+    float* out[kMaxTransposeJobs];
+    int rows[kMaxTransposeJobs], cols[kMaxTransposeJobs], ld_in[kMaxTransposeJobs], ld_out[kMaxTransposeJobs];
+    unsigned block0[kMaxTransposeJobs];
+};
+
+__global__ __launch_bounds__(256) void transpose_multi_f32(const TransposeJobs jobs) {
+    __shared__ float tile[64][65];
+    int k = 0;
+    while (k + 1 < jobs.n && blockIdx.x >= jobs.block0[k + 1]) ++k;
+    const float* __restrict__ in = jobs.in[k];
+    float* __restrict__ out = jobs.out[k];
+    const int rows = jobs.rows[k], cols = jobs.cols[k], ld_in = jobs.ld_in[k], ld_out = jobs.ld_out[k];
+    const int tiles_c = (cols + 63) >> 6, b = (int)(blockIdx.x - jobs.block0[k]);
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int r0 = (b / tiles_c) * 64, c0 = (b % tiles_c) * 64;
+    for (int r = ty; r < 64; r += 4)
+        if (r0 + r < rows && c0 + tx < cols) tile[r][tx] = in[(size_t)(r0 + r) * ld_in + c0 + tx];
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4)
+        if (c0 + c < cols && r0 + tx < rows) out[(size_t)(c0 + c) * ld_out + r0 + tx] = tile[tx][c];
+}
+
 // partial column sums: block = 64 columns x 4 row lanes, gridDim.y row chunks -> ws[chunk][N]
 __global__ __launch_bounds__(256) void colsum_partial(const float* __restrict__ x, int M, int N, int ld, int chunk,
                                                       float* __restrict__ ws) {
@@ -313,6 +340,35 @@ extern "C" int hd_transpose_f32(const void* in, void* out, int64_t rows, int64_t
     transpose_f32<<<grid, 256, 0, (hipStream_t)st>>>((const float*)in, (float*)out, (int)rows, (int)cols, (int)ld_in,
                                                       (int)ld_out);
     return check_launch("hd_transpose_f32");
+}
+
+extern "C" int hd_transpose_multi_f32(const hd_transpose_job* jobs, int n_jobs, void* st) {
+    HD_REQUIRE(n_jobs >= 0 && n_jobs <= kMaxTransposeJobs && (jobs || n_jobs == 0),
+               "hd_transpose_multi_f32: between 0 and %d jobs per call", kMaxTransposeJobs);
+    TransposeJobs tj;
+    tj.n = 0;
+    uint64_t blocks = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const hd_transpose_job& j = jobs[i];
+        HD_REQUIRE(j.rows >= 0 && j.cols >= 0 && j.ld_in >= j.cols && j.ld_out >= j.rows, "hd_transpose_multi_f32: job %d: bad shape", i);
+        if (j.rows == 0 || j.cols == 0) continue;
+        HD_REQUIRE(j.in && j.out && j.in != j.out, "hd_transpose_multi_f32: job %d: null or aliased pointer", i);
+        HD_REQUIRE(j.rows < (1LL << 31) && j.cols < (1LL << 31) && j.ld_in < (1LL << 31) && j.ld_out < (1LL << 31),
+                   "hd_transpose_multi_f32: job %d: size exceeds int32", i);
+        const int k = tj.n++;
+        tj.in[k] = (const float*)j.in;
+        tj.out[k] = (float*)j.out;
+        tj.rows[k] = (int)j.rows;
+        tj.cols[k] = (int)j.cols;
+        tj.ld_in[k] = (int)j.ld_in;
+        tj.ld_out[k] = (int)j.ld_out;
+        tj.block0[k] = (unsigned)blocks;
+        blocks += (uint64_t)((j.rows + 63) / 64) * ((j.cols + 63) / 64);
+        HD_REQUIRE(blocks < (1ULL << 31), "hd_transpose_multi_f32: too many workgroups");
+    }
+    if (tj.n == 0) return HD_OK;
+    transpose_multi_f32<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)st>>>(tj);
+    return check_launch("hd_transpose_multi_f32");
 }
 
 extern "C" int64_t hd_colsum_workspace_floats(int64_t M, int64_t N) {

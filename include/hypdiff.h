@@ -391,6 +391,13 @@ int hd_gemm_tn_limbs_f32(const void* Aimg, const void* Bimg, void* C, void* cols
 /* out[cols, rows] = in[rows, cols]^T */
 int hd_transpose_f32(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out,
                      void* stream);
+/* Several transposes in one launch (at most 64 jobs): every W^T of a backward pass (autograd of F.linear, ddpm.py:17-27). */
+typedef struct hd_transpose_job {
+    const void* in;
+    void* out;
+    int64_t rows, cols, ld_in, ld_out;
+} hd_transpose_job;
+int hd_transpose_multi_f32(const hd_transpose_job* jobs, int n_jobs, void* stream);
 /* bias gradient: out[n] = sum_m x[m, n]; workspace of hd_colsum_workspace_floats(M,N) floats */
 int64_t hd_colsum_workspace_floats(int64_t M, int64_t N);
 int hd_colsum_f32(const void* x, void* out, int64_t M, int64_t N, int64_t ld, void* workspace, void* stream);

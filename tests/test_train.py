@@ -520,6 +520,9 @@ def test_hip_dgrad_epilogue_transpose_colsum():
     resid = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32)).cuda()
     wt = hag.transpose(w)
     assert torch.equal(wt, w.t().contiguous())
+    many = [torch.from_numpy(rs.standard_normal(sh).astype(np.float32)).cuda() for sh in [(70, 52), (1, 1), (513, 64), (65, 129)] * 17]
+    many[3] = many[3][:, :100]                                      # a row stride that is not the width
+    assert all(torch.equal(t, m.t().contiguous()) for t, m in zip(hag.transpose_multi(many), many))     # 68 jobs: two launches
     g, dzb = torch.empty(M, K, device="cuda"), torch.empty(M, K, device="cuda")
     hag.gemm_ex(dz, wt, None, resid, z, g, dzb, 3)
     g64 = dz.double().cpu() @ w.double().cpu() + resid.double().cpu()
