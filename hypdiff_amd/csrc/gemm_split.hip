@@ -306,7 +306,8 @@ static int gemm_bf16x3_impl(const void* A, const void* W, const void* bias, cons
                                                              (const float*)aux, (float*)C, (float*)C2, (int)M, (int)N, (int)ldc, epi);
         return check_launch("hd_gemm_f32_bf16x3_splitk");
     }
-    int width = 128;
+    // 128x64 tiles where 128x128 ones would leave CUs without a workgroup (M = 4096, N = 512: 128 -> 256 workgroups)
+    int width = (int64_t)tiles_m * ((N + 127) / 128) < 256 ? 64 : 128;
     if (const char* e = getenv("HD_GEMM_SPLIT_TUNE")) {      // tuning hook: "n" = 128x64 tile, "w" = 128x128
         if (e[0] == 'n') width = 64; else if (e[0] == 'w') width = 128;
     }
