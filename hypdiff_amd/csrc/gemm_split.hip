@@ -264,9 +264,12 @@ __global__ __launch_bounds__(256) void splitk_epilogue(const float* __restrict__
 // 200 x 512 x 512 is 16 tiles of 16 slabs, 57 us of exposed load latency on 16 CUs)
 inline int splitk_splits(int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = ((M + BM - 1) / BM) * ((N + 63) / 64), nk = (K + BK - 1) / BK;
-    if (tiles >= 64 || nk < 4) return 1;
-    int64_t s = 256 / tiles;
-    s = s < nk / 2 ? s : nk / 2;
+    if (nk < 4) return 1;
+    // few tiles: up to 256 workgroups of >= 2 slabs; a chip's worth of tiles with a long K (config 4's 2708-wide
+    // identity features: 176 tiles of 85 slabs): up to 512 workgroups of >= 16 slabs
+    int64_t s = tiles < 64 ? 256 / tiles : 512 / tiles;
+    const int64_t cap = tiles < 64 ? nk / 2 : nk / 16;
+    s = s < cap ? s : cap;
     return (int)(s < 1 ? 1 : (s > 16 ? 16 : s));
 }
 

@@ -277,8 +277,15 @@ def gemm(a, w, bias=None, epi=0, resid=None, out=None):
     if ev is not None:          # bench.py: live HIP-event timing of the dominant kernel
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.call(gemm_symbol(), _p(a), _p(w), _p(bias), _p(resid), None, _p(out), None, M, N, a.shape[1], a.stride(0),
-              w.stride(0), out.stride(0), epi, _stream())
+    sym = gemm_symbol()
+    nws = _lib.load().hd_gemm_splitk_workspace_floats(M, N, a.shape[1]) if sym == "hd_gemm_f32_bf16x3" else 0
+    if nws > 0:       # few tiles or a long K on a chip's worth of tiles: the K range is split over workgroups
+        ws = torch.empty(nws, dtype=torch.float32, device=a.device)
+        _lib.call(sym + "_splitk", _p(a), _p(w), _p(bias), _p(resid), None, _p(out), None, M, N, a.shape[1], a.stride(0),
+                  w.stride(0), out.stride(0), epi, _p(ws), _stream())
+    else:
+        _lib.call(sym, _p(a), _p(w), _p(bias), _p(resid), None, _p(out), None, M, N, a.shape[1], a.stride(0),
+                  w.stride(0), out.stride(0), epi, _stream())
     if ev is not None:
         e1.record()
         ev.append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N),
