@@ -237,13 +237,24 @@ __global__ __launch_bounds__(kBlock) void row_stream(const T* __restrict__ in, T
     const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
     const bool hb = (op == S_HB_PROJ || op == S_HB_EXPMAP0 || op == S_HB_LOGMAP0);
+    // fp32 rows of 16-byte multiples (config 4's 2708-wide identity features): 16-byte accesses in both sweeps
+    const bool vec4 = sizeof(T) == 4 && !hb && (d & 3) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
     for (int64_t row = wave; row < n; row += nwaves) {
         const T* x = in + row * d;
         T ss = T(0);
-        for (int64_t i = lane + (hb ? 64 : 0); i < d; i += 64) ss += x[i] * x[i];
-        if (hb) {       // first 64 columns without the time coordinate
-            const int64_t i = lane;
-            if (i >= 1 && i < d) ss += x[i] * x[i];
+        if (vec4) {
+            const float4* xv = reinterpret_cast<const float4*>(x);
+            for (int64_t i = lane; i < (d >> 2); i += 64) {
+                const float4 q = xv[i];
+                ss += (T)(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+            }
+        } else {
+            for (int64_t i = lane + (hb ? 64 : 0); i < d; i += 64) ss += x[i] * x[i];
+            if (hb) {       // first 64 columns without the time coordinate
+                const int64_t i = lane;
+                if (i >= 1 && i < d) ss += x[i] * x[i];
+            }
         }
         ss = group_sum<64>(ss);
         const T nrm = hd_sqrt(ss);
@@ -281,6 +292,16 @@ __global__ __launch_bounds__(kBlock) void row_stream(const T* __restrict__ in, T
             } break;
         }
         T* y = out + row * d;
+        if (vec4) {
+            const float4* xv = reinterpret_cast<const float4*>(x);
+            float4* yv = reinterpret_cast<float4*>(y);
+            const float ff = (float)f;
+            for (int64_t i = lane; i < (d >> 2); i += 64) {
+                const float4 q = xv[i];
+                yv[i] = make_float4(q.x * ff, q.y * ff, q.z * ff, q.w * ff);
+            }
+            continue;
+        }
         for (int64_t i = lane; i < d; i += 64) y[i] = (set_t0 && i == 0) ? t0 : x[i] * f;
     }
 }
