@@ -13,7 +13,7 @@ ddpm.py:71-85).  Here one Function covers a whole Linear(+GELU)(+residual) stack
                        g  = dz @ W (+ skip gradient), and dz of the layer below =
                             g * gelu'(z_below) from the same accumulators (hd_gemm_f32_ex, epi 3)
 
-PyTorch owns memory, the autograd graph, the optimizer and RNG; nothing else.
+PyTorch owns memory, the autograd graph and RNG (and the optimizer unless dist.BucketAdam is used); nothing else.
 """
 import torch
 
