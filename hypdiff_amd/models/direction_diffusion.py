@@ -442,7 +442,9 @@ class diffusion(nn.Module):
         """:335-363 training loss; differentiable w.r.t. the denoiser parameters
         (loss.backward() runs hd_gemm_tn_f32 / hd_gemm_f32_ex kernels, hypdiff_amd/autograd.py).
         `t` / `noise` optionally inject the draws."""
+        x_in = x
         x = x.to(torch.float64)
+        fresh = x.data_ptr() != x_in.data_ptr()       # a cast copy of our own: nobody can observe the in-place update
         b, n = x.shape
         t = torch.randint(0, self.num_timesteps, (b,), device=x.device).long() if t is None else t
         own_noise = noise is not None                 # the caller's tensor: tran_direction flips its signs in place
@@ -450,6 +452,9 @@ class diffusion(nn.Module):
         direction = self.directions(u0)
         if not restrict:
             x_start = self.manifold.logmap0(x, c=1.0)
+        elif fresh:
+            centres = u0 if torch.is_tensor(u0) else torch.stack(list(u0))
+            x_start = ops.map_at("hd_pb_logmap_at", centres, ops.labels_dev(labels, x.device), x, 1.0)
         else:
             x_start = self._logmap_centres(x, labels, u0)
         if self.fuse_prepass and graphset and x_start.dtype == torch.float64 and t.dtype == torch.int64 and noise.is_contiguous() \
