@@ -6,18 +6,27 @@ One "step" = one pass of the hot path over one batch of synthetic input:
     SynEgo1000-shaped graph set (1197 graphs, sum N = 15 777 rows), followed by one
     direction-diffusion p_sample step (mlp denoiser + fused update, T = 1000 tables)
     over the (sum N, 512) latents.
-value = rows processed by all ranks / wall time (inputs resident in HBM before timing).  The two phases of a
-step read different inputs, so the encode is issued on a second HIP stream and joined before the step ends
-(`--one-stream`: both on one stream; reported as the `one_stream` secondary otherwise).
+value = rows processed by all ranks / wall time (inputs resident in HBM before timing).  The headline arrangement is
+software-pipelined across batches: step i encodes graph-set batch i % 2 on a second HIP stream while p_sample advances the
+latents of the OTHER batch on the main stream (the two phases of one batch are data-dependent in the reference pipeline,
+diff.py:85-127; those of two batches are not); the streams are joined per step.  `--one-stream`: both phases on one
+stream (what a caller without a pipeline gets; reported as the `one_stream` secondary otherwise).  No priming steps:
+`warmup_effective` counts every untimed step issued before the K timed ones.
 
     python bench.py --gpus N --steps K --warmup W
-For N > 1 launch one rank per GPU (torch.distributed.run); each rank owns its own
+N > 1: when WORLD_SIZE is not set this process is only a LAUNCHER -- it touches no GPU, starts N fresh rank processes
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set), forwards rank 0's JSON line and exits
+non-zero if any rank does.  Under torch.distributed.run (WORLD_SIZE set) it is a rank.  Each rank owns its own
 graph-set shard of the same size (weak scaling, no data-path collective in the step).
+`--dry --backend gloo`: the launcher / rendezvous / JSON merge without a GPU or a kernel (tests/test_bench_launcher.py).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 import types
 
@@ -71,13 +80,13 @@ def timed_steps(w, T, steps, warmup, barrier, ops, dist, device, instrument=Fals
     durations of the roofline come from a second pass over the same K steps."""
     with torch.no_grad():
         for i in range(warmup):
-            one_step(w, T - 1 - (i % T))
+            one_step(w, T - 1 - (i % T), None, i)
         barrier()
         ops.GEMM_EVENTS = [] if instrument else None
         phase = [] if instrument else None
         t0 = time.perf_counter()
         for i in range(steps):
-            one_step(w, T - 1 - (i % T), phase)
+            one_step(w, T - 1 - (i % T), phase, i)
         barrier()
         elapsed = time.perf_counter() - t0
         events, ops.GEMM_EVENTS = ops.GEMM_EVENTS or [], None
@@ -88,40 +97,61 @@ def timed_steps(w, T, steps, warmup, barrier, ops, dist, device, instrument=Fals
     return elapsed, events, phase or []
 
 
-def build_workload(dim, T, seed, device):
-    from hypdiff_amd import ops, workloads
-    from hypdiff_amd.models.direction_diffusion import diffusion
-    from hypdiff_amd.models.encoders import HGCN
+def host_batch(seed, dim, feat=20):
+    """One synthetic SynEgo1000-shaped graph-set batch, host side only (numpy): block-diagonal
+    normalised COO, identity features with the Hyperboloid zero time column, labels, centres, latents."""
+    from hypdiff_amd import workloads
     mats, sizes = workloads.ego_graph_set(seed=seed)
-    feat = 20
     idx, val, shape, feats = workloads.batch_graph_set(mats, sizes, feat)
     n = shape[0]
+    x = np.concatenate([np.zeros((n, 1), np.float32), feats], axis=1)      # base_models.py:79-81
+    rs = np.random.RandomState(seed)
+    labels = rs.randint(0, 3, size=n).astype(np.int64)                     # host array, as the reference holds it
+    u0 = (rs.standard_normal((3, dim)) * 0.05).astype(np.float32)
+    img = rs.standard_normal((n, dim))                                     # fp64 state, as after step 1
+    return dict(idx=idx, val=val, shape=shape, x=x, labels=labels, u0=u0, img=img, n=n, nnz=idx.shape[1], feat=feat + 1)
+
+
+def build_workload(dim, T, seed, device):
+    """Two batches of the same shape (seeds `seed`, `seed + 7919`): the pipelined headline encodes one while
+    p_sample advances the latents of the other.  Both are resident in HBM before any timing starts."""
+    from hypdiff_amd import ops
+    from hypdiff_amd.models.direction_diffusion import diffusion
+    from hypdiff_amd.models.encoders import HGCN
+    hosts = [host_batch(seed, dim), host_batch(seed + 7919, dim)]
+    feat = hosts[0]["feat"]
     torch.manual_seed(seed)
-    args = types.SimpleNamespace(manifold="Hyperboloid", c=1.0, cuda=0, device=device, feat_dim=feat + 1, dim=dim,
+    args = types.SimpleNamespace(manifold="Hyperboloid", c=1.0, cuda=0, device=device, feat_dim=feat, dim=dim,
                                  num_layers=2, act="relu", dropout=0.0, bias=0, use_att=0, local_agg=0)
     enc = HGCN(torch.tensor([1.0], device=device), args).to(device).eval()
     diff = diffusion(types.SimpleNamespace(r=2.0, t=1.0), dim, num_timesteps=T).eval()
-    adj = torch.sparse_coo_tensor(torch.from_numpy(idx).to(device), torch.from_numpy(val).to(device), shape,
-                                  check_invariants=False)
-    x = torch.from_numpy(feats).to(device)
-    x = torch.cat([torch.zeros_like(x[:, :1]), x], dim=1).contiguous()     # base_models.py:79-81
-    rs = np.random.RandomState(seed)
-    labels = rs.randint(0, 3, size=n).astype(np.int64)                     # host array, as the reference holds it
-    u0 = torch.from_numpy((rs.standard_normal((3, dim)) * 0.05).astype(np.float32)).to(device)
-    img = torch.from_numpy(rs.standard_normal((n, dim))).to(device)        # fp64 state, as after step 1
-    with torch.no_grad():
-        direction = diff.directions(u0)
-        ops.csr_of(adj)
-    labels_d = ops.labels_dev(labels, device)       # one upload, as p_sample_loop does for its T steps
-    host = dict(idx=idx, val=val, shape=shape, x=x.cpu(), labels=labels, u0=u0.cpu(), img=img.cpu())
-    return dict(enc=enc, diff=diff, adj=adj, x=x, labels=labels_d, u0=u0, img=img, direction=direction, n=n,
-                nnz=idx.shape[1], host=host, feat=feat + 1)
+    batches = []
+    for hb in hosts:
+        adj = torch.sparse_coo_tensor(torch.from_numpy(hb["idx"]).to(device), torch.from_numpy(hb["val"]).to(device),
+                                      hb["shape"], check_invariants=False)
+        x = torch.from_numpy(hb["x"]).to(device).contiguous()
+        u0 = torch.from_numpy(hb["u0"]).to(device)
+        img = torch.from_numpy(hb["img"]).to(device)
+        with torch.no_grad():
+            direction = diff.directions(u0)
+            ops.csr_of(adj)
+        labels_d = ops.labels_dev(hb["labels"], device)   # one upload, as p_sample_loop does for its T steps
+        batches.append(dict(adj=adj, x=x, labels=labels_d, u0=u0, img=img, direction=direction))
+    h0 = hosts[0]
+    host = dict(idx=h0["idx"], val=h0["val"], shape=h0["shape"], x=torch.from_numpy(h0["x"]), labels=h0["labels"],
+                u0=torch.from_numpy(h0["u0"]), img=torch.from_numpy(h0["img"]))
+    w = dict(batches[0])
+    w.update(enc=enc, diff=diff, batches=batches, n=h0["n"], nnz=h0["nnz"], nnz_other=hosts[1]["nnz"], host=host,
+             feat=feat)
+    return w
 
 
-def one_step(w, t, ev=None):
-    """One step.  The two phases read different inputs (node features + adjacency / current
-    latents); when w["side_stream"] is set (the headline arrangement; `--one-stream` turns it off) the encode
-    is issued on that stream and joined before the step returns."""
+def one_step(w, t, ev=None, i=0):
+    """One step: HGCN encode of one graph-set batch + one p_sample over (sum N, dim) latents.
+
+    One stream (w["side_stream"] unset): both phases of batch 0 back to back.  Two streams (the
+    headline): software pipeline ACROSS batches -- step i encodes batch i % 2 on the side stream while
+    p_sample advances the latents of batch (i + 1) % 2 on the main stream; joined before the step returns."""
     side = w.get("side_stream")
     if side is None:
         if ev is not None:
@@ -135,11 +165,12 @@ def one_step(w, t, ev=None):
             e[2].record()
             ev.append(e)
         return h, pred
+    be, bd = w["batches"][i % 2], w["batches"][(i + 1) % 2]
     main = torch.cuda.current_stream()
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        h = w["enc"].encode(w["x"], w["adj"])
-    pred, x0 = w["diff"].p_sample(w["img"], None, 1, w["direction"], w["labels"], w["u0"], t, None, True)
+        h = w["enc"].encode(be["x"], be["adj"])
+    pred, x0 = w["diff"].p_sample(bd["img"], None, 1, bd["direction"], bd["labels"], bd["u0"], t, None, True)
     main.wait_stream(side)
     h.record_stream(main)
     return h, pred
@@ -206,14 +237,18 @@ def train_leg(w, dim, device, steps, warmup, barrier, dist):
         diff.sync_moments = True
     tr = DataParallelTrainer(diff.mlp, lr=1e-3)
     loss_fn = lambda: diff(emb, None, w["host"]["labels"], w["u0"], restrict=True, graphset=True)
+    from hypdiff_amd import dist as hdist
     for _ in range(warmup):
         tr.step(loss_fn)
     barrier()
+    hdist.WAIT_EVENTS = []
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = tr.step(loss_fn)
     barrier()
     dt = time.perf_counter() - t0
+    waits, hdist.WAIT_EVENTS = hdist.WAIT_EVENTS, None
+    exposed_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in waits) / steps
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -223,7 +258,13 @@ def train_leg(w, dim, device, steps, warmup, barrier, dist):
     return {"metric": "denoiser training node-steps/s (forward + backward + gradient all-reduce + Adam)",
             "value": w["n"] * steps * world / dt, "unit": "node-steps/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
             "grad_bucket_bytes": int(tr.bucket.flat.numel() * 4), "final_loss": float(loss),
-            "parallelism": "data-parallel x%d, one flat all-reduce per step" % world}
+            "allreduce_bytes_per_step_per_gpu": (int(tr.bucket.flat.numel() * 4) + 24) if world > 1 else 0,
+            "allreduce_chunks": len(tr.bucket.chunks),
+            "exposed_collective_ms_per_step": exposed_ms,
+            "exposed_note": "HIP events on the compute stream around the wait for the gradient chunks (rank 0): time the "
+                            "all-reduce was not hidden behind the backward GEMMs; 0 in a world of one",
+            "parallelism": "data-parallel x%d, gradient bucket all-reduced in %d chunks started from the backward pass"
+                           % (world, len(tr.bucket.chunks))}
 
 
 def sharded_leg(device, rank, world, steps, warmup, barrier, dist):
@@ -252,11 +293,14 @@ def sharded_leg(device, rank, world, steps, warmup, barrier, dist):
         for _ in range(warmup):
             hdist.sharded_hgcn_encode(enc, x, sh)
         barrier()
+        hdist.WAIT_EVENTS = []
         t0 = time.perf_counter()
         for _ in range(steps):
             h = hdist.sharded_hgcn_encode(enc, x, sh)
         barrier()
         dt = time.perf_counter() - t0
+        waits, hdist.WAIT_EVENTS = hdist.WAIT_EVENTS, None
+        exposed_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in waits) / steps
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -266,7 +310,98 @@ def sharded_leg(device, rank, world, steps, warmup, barrier, dist):
             "steps": steps, "ms_per_step": dt / steps * 1e3, "rows_total": n, "rows_per_gpu": rows_per_rank, "dim": d,
             "nnz_per_gpu": nnz_loc, "hub_rows_per_gpu": int(csr.n_long), "finite": bool(torch.isfinite(h).all()),
             "allgather_bytes_per_layer_per_gpu": rows_per_rank * d * 4 * (world - 1),
+            "exposed_collective_ms_per_step": exposed_ms,
+            "exposed_note": "HIP events on the compute stream around each slab's wait (rank 0, summed over 2 layers x 4 "
+                            "slabs): all-gather time not hidden behind the SpMM of the previous slab; 0 in a world of one",
             "parallelism": "rows sharded x%d, tangent all-gather per layer in 4 column slabs overlapped with the SpMM" % world}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv, dry):
+    """`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process stays a LAUNCHER.  It makes no GPU
+    call (torch.cuda.device_count() does not initialise the device on this image; nothing of hypdiff_amd is imported),
+    starts N fresh rank processes of this same script -- one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT in their environment, exactly what torch.distributed.run would set -- and waits.  Rank 0's stdout is
+    forwarded (its last line is the JSON line); the other ranks' stdout goes to stderr.  Exit status: the first
+    non-zero status of any rank (the remaining ranks are then terminated by PID), else 0."""
+    if not dry:
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write(f"bench.py: --gpus {n} but only {have} GPU(s) visible\n")
+            return 2
+    port = _free_port()
+    procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HD_BENCH_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=out0 if r == 0 else sys.stderr))
+    rc = 0
+    live = set(range(n))
+    while live:
+        time.sleep(0.1)
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                sys.stderr.write(f"bench.py: rank {r} exited with status {code}; stopping the other ranks\n")
+                for q in live:
+                    procs[q].terminate()          # exact PIDs of the children started above
+    out0.seek(0)
+    sys.stdout.write(out0.read())
+    sys.stdout.flush()
+    return rc if rc >= 0 else 128 - rc
+
+
+def dry_run(a, rank, world):
+    """`--dry`: everything around the kernels -- rank environment, process group (`--backend`), host-side workload
+    build of this rank's shard, barriers, max-over-ranks timing, per-rank gather, the JSON line -- without touching a
+    GPU.  The "step" is a host checksum of the shard's adjacency, so value is NOT a performance number."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(a.backend, rank=rank, world_size=world)
+    hb = host_batch(1432 + rank, min(a.dim, 8))
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    chk = 0
+    for _ in range(a.steps):
+        chk = int(hb["idx"].sum() % 1000003)
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    rows = torch.tensor([hb["n"]], dtype=torch.int64)
+    per_rank = [rows.clone() for _ in range(world)]
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_gather(per_rank, rows)
+    rows_per_gpu = [int(r.item()) for r in per_rank]
+    if rank == 0:
+        print(json.dumps({"metric": "latent node-steps/sec (HGCN encode + DDPM step)",
+                          "value": None, "unit": "node-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": float(el.item()) / a.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
+                          "data": "synthetic", "dry": True,
+                          "config": {"workload": "DRY RUN: launcher / rendezvous / JSON merge only, no kernel ran; "
+                                                 "value is not a performance number",
+                                     "rows_per_gpu": rows_per_gpu, "backend": a.backend, "checksum": chk,
+                                     "launched_by": "bench.py launcher" if os.environ.get("HD_BENCH_LAUNCHED") else
+                                                    ("external launcher" if world > 1 else "single process")}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -278,27 +413,36 @@ def main():
     ap.add_argument("--timesteps", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--one-stream", action="store_true",
-                    help="issue both phases of a step on ONE HIP stream (default: encode on a second stream, joined per "
-                         "step -- the two phases read different inputs)")
+                    help="headline with both phases of a step on ONE HIP stream (default: software pipeline across two "
+                         "batches on two streams, joined per step)")
     ap.add_argument("--no-overlap-leg", action="store_true",
                     help="skip the secondary leg that repeats the steps with the other stream arrangement")
     ap.add_argument("--no-exact-leg", action="store_true", help="skip the comparison legs on the other fp32 GEMM kernels")
     ap.add_argument("--train-steps", type=int, default=20, help="steps of the secondary training leg (0 = skip)")
     ap.add_argument("--sharded-steps", type=int, default=5, help="steps of the secondary row-sharded leg (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="headline steps only (profiling runs)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo with --dry)")
+    ap.add_argument("--dry", action="store_true", help="no GPU, no kernels: launcher / rendezvous / JSON plumbing only")
     a = ap.parse_args()
     if a.no_secondary:
         a.no_overlap_leg = a.no_exact_leg = True
         a.train_steps = a.sharded_steps = 0
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:], a.dry))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.dry:
+        sys.exit(dry_run(a, rank, world))
+    if a.gpus != world:
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: running the {world} rank(s) of the launcher\n")
     dist = None
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(a.backend, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     device = f"cuda:{local_rank if world > 1 else 0}"
@@ -313,46 +457,49 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Headline: the encode of a step is issued on a second HIP stream and joined before the step ends (its HBM-bound
-    # kernels run in the partly empty tile rounds of the denoiser GEMMs: 0.67-0.69 against 0.72-0.74 ms on one stream
-    # since the single-buffer GEMM of round 2; before that it measured no gain).  The per-kernel pass below stays on one
-    # stream: a kernel's duration there is its own, not that of two kernels sharing the chip.
+    # Headline: software pipeline across two batches -- the encode of batch i % 2 on a second HIP stream while p_sample
+    # advances the other batch's latents (the HBM-bound encode kernels run in the partly empty tile rounds of the
+    # denoiser GEMMs); joined per step.  The per-kernel pass below stays on one stream: a kernel's duration there is
+    # its own, not that of two kernels sharing the chip.  No priming steps: what runs before the K timed steps is the
+    # secondary leg in the other arrangement (a leg of its own, reported) and the W warm-up steps; `warmup_effective`
+    # counts both.
     side = None if a.one_stream else torch.cuda.Stream()
     rows_total = w["n"] * a.steps * world
     other = None
+    untimed_before = 0
     if not a.no_overlap_leg:
         # secondary, run FIRST: the same K steps in the other stream arrangement.  It comes before the headline on
-        # purpose and the line says so (config.order): a run of 25 steps is 18 ms, less than the chip takes to leave its
-        # idle clocks, and whichever leg came first measured 8-10 % slow in short runs (--steps 20 --warmup 5: 0.76 ms
-        # first against 0.70 in a 200-step run; the leg after it 0.75 in both).  The headline's own W warm-up steps and
-        # exactly K timed steps are unchanged.
+        # purpose and the line says so (config.order, warmup_effective): a run of 25 steps is 18 ms, less than the chip
+        # takes to leave its idle clocks, and whichever leg came first measured 8-10 % slow in short runs.
         if side is None:
             w["side_stream"] = torch.cuda.Stream()
         try:
             k3 = max(a.steps, 100)                     # its own step count: at least 100, i.e. >= 70 ms of load
-            el3, _, _ = timed_steps(w, T, k3, min(a.warmup, 3), barrier, ops, dist, device)
+            w3 = min(a.warmup, 3)
+            el3, _, _ = timed_steps(w, T, k3, w3, barrier, ops, dist, device)
+            untimed_before += k3 + w3
             other = ("two_streams" if side is None else "one_stream",
                      {"value": w["n"] * k3 * world / el3, "unit": "node-steps/s", "steps": k3, "ms_per_step": el3 / k3 * 1e3,
-                      "note": ("same steps with encode and p_sample of a step on two HIP streams, joined per step"
-                               if side is None else "same steps with both phases on one HIP stream") +
-                              "; run before the headline steps (first on the idle chip)"})
+                      "note": ("same steps as a software pipeline across two batches on two HIP streams, joined per step"
+                               if side is None else "both phases of ONE batch on one HIP stream: what a caller without a "
+                               "pipeline gets") + "; run before the headline steps (first on the idle chip)"})
         finally:
             w.pop("side_stream", None)
-    # the second stream's first ~40 steps run ~5 % slow (tools/short_runs.py: 5 + 20 steps measure 0.693, 0.666, 0.658,
-    # 0.657 ms in four consecutive runs, 0.652 over 200): short runs get the difference as untimed priming steps ahead of
-    # their own W warm-up steps; stated in config.priming_steps
-    prime = max(0, 40 - a.warmup) if side is not None else 0
     if side is not None:
         w["side_stream"] = side
     try:
-        if prime:
-            with torch.no_grad():
-                for i in range(prime):
-                    one_step(w, T - 1 - (i % T))
         elapsed, _, _ = timed_steps(w, T, a.steps, a.warmup, barrier, ops, dist, device)
     finally:
         w.pop("side_stream", None)
+    untimed_before += a.warmup
     el_inst, events, phase = timed_steps(w, T, a.steps, min(a.warmup, 3), barrier, ops, dist, device, instrument=True)
+    rows_per_gpu = [w["n"]]
+    if dist is not None:
+        mine = torch.tensor([w["n"]], dtype=torch.int64, device=device)
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+        rows_per_gpu = [int(r.item()) for r in per_rank]
+        rows_total = sum(rows_per_gpu) * a.steps
 
     # dominant kernel: the fp32 GEMM of the denoiser / HypLinear (live HIP-event timing per launch)
     per = gemm_summary(events)
@@ -363,36 +510,41 @@ def main():
     # HBM bytes per launch from the PMC passes of the same command (profiles/, collected with
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE; cannot be sampled from inside the process)
     traffic, traffic_src = None, None
-    tp = os.path.join(ROOT, "profiles", "r02_bench_hbm_traffic.json")
-    if os.path.exists(tp):
+    tp = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_bench_hbm_traffic.json") for r in (3, 2))
+               if os.path.exists(q)), None)
+    if tp is not None:
         try:
             ks = json.load(open(tp))["kernels"]
             hit = [v for k, v in ks.items() if k.startswith(GEMM_PMC_KEYS[dom])]
             if hit:
                 traffic = int(sum(v["hbm_bytes_corrected"] * v["launches"] for v in hit) / sum(v["launches"] for v in hit))
-                traffic_src = "profiles/r02_bench_hbm_traffic.json (rocprofv3 PMC, per-launch mean)"
+                traffic_src = "profiles/%s (rocprofv3 PMC, per-launch mean)" % os.path.basename(tp)
         except Exception:
             traffic = None
     gemm_ms = sum(v["ms"] for v in per.values())
     out = {
         "metric": "latent node-steps/sec (HGCN encode + DDPM step)",
         "value": rows_total / elapsed, "unit": "node-steps/s", "n_gpus": world, "steps": a.steps,
-        "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "warmup": a.warmup, "warmup_effective": untimed_before,
+        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
         "dtype": DTYPES[ops.GEMM_MODE],
         "data": "synthetic",
         "config": {"workload": "configs[1]: SynEgo1000-shaped graph set (1197 ego graphs, sum N=%d, nnz=%d), "
                                "Hyperboloid c=1 HGCN encode (21->%d->%d) + direction-diffusion p_sample "
                                "(mlp denoiser, T=%d tables)" % (w["n"], w["nnz"], a.dim, a.dim, T),
-                   "rows_per_gpu": w["n"], "dim": a.dim, "timesteps": T, "parallelism": "graph-set shards x%d" % world,
-                   "gemm_mode": ops.GEMM_MODE,
-                   "streams": "one HIP stream" if side is None else
-                              "two HIP streams (encode || p_sample inside a step, joined per step)",
-                   "priming_steps": prime,
-                   "order": ("secondary leg in the other stream arrangement (max(K, 100) steps), then " if other else "") +
-                            ("%d untimed priming steps in the headline arrangement (40 - W: the second stream's first ~40 "
-                             "steps run ~5 %% slow), then " % prime if prime else "") +
-                            "W warm-up + K timed headline steps, then the instrumented per-kernel pass, then the other legs"},
+                   "rows_per_gpu": rows_per_gpu, "dim": a.dim, "timesteps": T,
+                   "parallelism": "graph-set shards x%d" % world, "gemm_mode": ops.GEMM_MODE,
+                   "launched_by": "bench.py launcher" if os.environ.get("HD_BENCH_LAUNCHED") else
+                                  ("external launcher" if world > 1 else "single process"),
+                   "streams": "one HIP stream (both phases of one batch back to back)" if side is None else
+                              "two HIP streams, software-pipelined across batches: step i encodes batch i % 2 while "
+                              "p_sample advances the latents of batch (i + 1) % 2; joined per step",
+                   "priming_steps": 0,
+                   "order": ("secondary leg in the other stream arrangement (%d untimed-for-the-headline steps), then "
+                             % (untimed_before - a.warmup) if other else "") +
+                            "W warm-up + K timed headline steps, then the instrumented per-kernel pass, then the other legs; "
+                            "warmup_effective = every step issued before the K timed ones"},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                      "traffic_unit": "HBM bytes per launch (mean)", "traffic_source": traffic_src,

@@ -24,6 +24,26 @@ import torch.distributed as dist
 # tests: issue the collectives even in a world of ONE rank, so that the RCCL code path executes on a
 # single-GPU box (a world of one normally short-circuits every collective)
 FORCE_COLLECTIVES = False
+# bench.py: set to a list to have every wait for a collective bracketed by two HIP events on the compute stream,
+# appended as (kind, event_before, event_after).  The first event completes when the kernels ahead of the wait have
+# finished, the second when the collective has: the difference is the EXPOSED collective time (what the overlap
+# did not hide).  Device tensors only; None = no events (the default: a record is a packet of its own in the queue).
+WAIT_EVENTS = None
+
+
+def _timed_wait(kind, works, on_cuda):
+    ev = WAIT_EVENTS
+    works = [w for w in works if w is not None]
+    if ev is None or not on_cuda or not works:
+        for w in works:
+            w.wait()
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for w in works:
+        w.wait()
+    e1.record()
+    ev.append((kind, e0, e1))
 
 
 def _collective(group=None):
@@ -157,8 +177,7 @@ class GradBucket:
             if left > 0:
                 self._launch(c)
         self._left = {}
-        for w in self._works:
-            w.wait()
+        _timed_wait("allreduce", self._works, self.flat.is_cuda)
         self._works = []
 
     def allreduce_mean_(self, group=None, async_op=False):
@@ -436,8 +455,7 @@ def shard_aggregate_slabs(layer, csr, slabs, n_loc):
     full0 = slabs[0][2]
     sup = torch.empty(csr.shape[0], d, dtype=full0.dtype, device=full0.device)
     for lo, hi, full, work in slabs:
-        if work is not None:
-            work.wait()                         # the compute stream waits for THIS slab's collective only
+        _timed_wait("allgather", [work], full.is_cuda)   # the compute stream waits for THIS slab's collective only
         ops.spmm_into(csr, full, sup, lo)
     out = ops.agg_tail(man.abi, sup, layer.agg.c, layer.hyp_act.c_out if code is not None else None, code)
     if code is None:
