@@ -22,6 +22,12 @@ class HdChainLayer(ctypes.Structure):
                 ("add_emb", c_int32)]
 
 
+class HdMlpChainLayer(ctypes.Structure):
+    """struct hd_mlp_chain_layer of include/hypdiff.h"""
+    _fields_ = [("W", c_void_p), ("bias", c_void_p), ("out_image", c_void_p), ("out_f32", c_void_p), ("N", c_int64),
+                ("K", c_int64), ("ldc", c_int64), ("epi", c_int32)]
+
+
 class HdPackJob(ctypes.Structure):
     """struct hd_pack_job of include/hypdiff.h"""
     _fields_ = [("src", c_void_p), ("image", c_void_p), ("ld", c_int64), ("rows", c_int64), ("cols", c_int64),
@@ -61,6 +67,7 @@ SIZE_QUERIES = {
     "hd_smallk_image_bytes": [I64],
     "hd_chain_image_bytes": [I64, I64],
     "hd_chain_workspace_bytes": [],
+    "hd_mlp_chain_workspace_bytes": [I64, c_int],
 }
 
 # name -> argtypes; names ending in "*" exist as _f32 and _f64
@@ -94,6 +101,8 @@ SIGNATURES = {
     "hd_chain_pack_w_f32": [P, I64, I64, I64, P, P],
     "hd_linear_chain_small_f32": [P, I64, I64, POINTER(HdChainLayer), c_int, P, P, I64, P, I64, P, I64, P],
     "hd_chain_failed": [P, P],
+    "hd_mlp_chain_limbs_f32": [P, I64, POINTER(HdMlpChainLayer), c_int, P, I64, P],
+    "hd_mlp_chain_failed": [P, P],
     "hd_hb_linear_smallk_bf16x3_f32": [P, P, P, I64, I64, I64, HdCurv, c_int, P],
     "hd_csr_from_coo": [P, P, I64, I64, I64, P, P, P, P],
     "hd_adj_count": [P, P, I64, P, P, P],

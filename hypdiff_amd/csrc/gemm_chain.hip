@@ -1,0 +1,623 @@
+// A stack of nn.Linear (+ bias, + exact-erf GELU) layers over MANY rows as ONE persistent launch on the bf16 matrix
+// cores: the mlp denoiser of models/direction_diffusion.py:56-69 (D+1 -> 800 -> 900 -> 800 -> 700 -> D over all
+// latent rows of a sampling step).  Arithmetic, limb images and the K loop are those of csrc/gemm_limbs.hip
+// (fp32-faithful 3-limb split, 6 exact limb products per fp32 product, 128 x 64 tile, 4 wavefronts, one LDS
+// buffer, LDS-DMA staging); what is new is the schedule.
+//
+// An MLP is row-parallel: layer l + 1 of a 128-row block needs layer l of THAT row block only.  So instead of five
+// launches, each a whole number of tile rounds on 512 workgroup slots (1612 / 1860 / 1612 / 1364 / 992 tiles: 17 rounds
+// where the work is worth 14.5, and four launch ramps and drains), all 7440 tiles of the chain form one stream of
+// work items (layer, row block, column tile) that the resident workgroups pull from device-side queues.  The only
+// synchronisation is a counter per (layer, row block) that the tiles of a row block raise when their part of the
+// limb image is in memory; a tile of the next layer polls it before it stages its A operand.
+//
+//   * Eight queues, one per XCD; row block rb belongs to queue rb % 8, so the producer and the consumers of a
+//     row block's activations normally sit on one XCD.  A queue holds its items layer-major, then row block, then
+//     column tile (N fastest: the tiles running at the same time share A panels through that XCD's L2).  A
+//     workgroup pulls from the queue of the XCD it runs on (HW_REG_XCC_ID) and, when that is empty, from the others
+//     (work stealing: the XCDs do not finish together: 124 row blocks are 15.5 per XCD).
+//   * No deadlock whatever the residency: an item depends only on items EARLIER in its own queue, items are handed
+//     out in queue order, and a workgroup holds at most its current item and the one it pulled ahead.  Layer-major
+//     order puts ~200 items of the same queue between a tile and its consumers (64 run at once per XCD), so the
+//     poll is satisfied the first time in practice.  Every wait is bounded (2 s of wall clock): on a time-out the
+//     fail word is raised, every other wait ends at once, the launch runs to its end and the last workgroup fills
+//     the fp32 output with NaN.
+//   * Hand-off (MI355X_MICROARCH.md, "Valid forms"): the limb image is written with 16-byte `sc1` (write-through)
+//     stores -- a lane pair's two 8-byte halves of a chunk are brought into one lane by v_permlane16_swap --
+//     every storing wave waits vmcnt(0), the workgroup meets at a barrier, one lane adds to the counter
+//     (agent scope).  The consumer: one lane polls the counter (agent-scope load), issues the agent acquire
+//     (buffer_inv sc1), waits for it, the workgroup meets at a barrier, then LDS-DMA loads.  A region of an image is
+//     written once per launch and read only after its counter is complete.
+//   * Everything a tile needs to know about its successor is fetched while it multiplies, in its LAST five K slabs
+//     (an item reserved early would sit on its workgroup while others go idle at the end of the launch): the queue
+//     pull (a returning atomic), its decode, the counter poll (an atomic add of 0), the acquire, the hand-over to the
+//     other wavefronts -- one step per slab, each consuming what the previous one left in flight (one register,
+//     read after the vmcnt(0) that every slab starts with), each issued BEHIND that slab's staging loads, so no
+//     wavefront waits on a round trip and no load is delayed.  The successor's first slab then streams into LDS under
+//     the last multiply of the current tile, as in the per-layer kernel.
+//   * Nothing this launch writes stays dirty in an L2: the fp32 output goes out write-through as well, so the launch
+//     does not end on a cache write-back.  The last workgroup out is found in two levels (8 groups, then one word):
+//     512 adds to one word are ~6 us when the workgroups finish together.
+//   * The workspace (queue heads, counters) is zeroed by the LAST workgroup to leave, so the next launch on the
+//     same stream finds it clean; the caller zero-fills it once when it allocates it.
+#include "hd_common.cuh"
+#include "hd_gelu.cuh"
+#include "../../include/hypdiff.h"
+#include <stdlib.h>
+#include <type_traits>
+
+using namespace hd;
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMaxLayers = 8;
+constexpr int kTile = 4 * 3 * 128;               // 16-byte chunks of one (row block, K slab) tile of a limb image
+constexpr int BNT = 64;                          // tile 128 x 64, 2 x 2 wavefronts of 64 x 32
+constexpr int CH_A = 4 * 3 * 128, CH_W = 4 * 3 * BNT, CH_BUF = CH_A + CH_W;
+constexpr int QA = 6, QW = 3;                    // 1 KiB LDS-DMA pieces per wavefront and slab
+// workspace words (unsigned): queue head q at q * 32 (a 128-byte line each), then fail, exited, then the counters
+constexpr int WS_FAIL = 256, WS_EXITED = 257, WS_STAT = 260, WS_EXIT_GROUP = 288, WS_DONE = 288 + 256;   // WS_STAT..+3: slow paths, polls that failed (flag 8)
+constexpr uint64_t kTimeoutTicks = 200000000ull; // 2 s of the 100 MHz wall clock
+
+struct Layer {
+    const uint4* W;          // limb image of the weight (N, K)
+    const float* bias;       // N floats or null
+    uint4* out_img;          // limb image of the output (M, N), or null
+    float* out_f32;          // fp32 output (M, N) with row pitch ldc, or null
+    int N, nslab, tiles_n, nslab_out, epi, ldc;
+};
+struct ChainArgs {
+    Layer L[kMaxLayers];
+    const uint4* A0;         // limb image of the input (M, K_0)
+    unsigned* ws;
+    int n_layers, M, tiles_m;
+    int cum[kMaxLayers + 1]; // cum[l] = column tiles of layers < l (per row block)
+    int delay_ticks;         // start-up stagger of every second workgroup (0 = none)
+    unsigned long long* dbg; // HD_MLP_CHAIN_DEBUG_PTR: 8 wall-clock stamps per workgroup (probes), or null
+    int flags;               // debugging (HD_MLP_CHAIN_FLAGS): 4 = no pull-ahead (every successor resolved blocking), 8 = count slow paths
+};
+
+__device__ __forceinline__ unsigned pk_bf16(float x, float y) {
+    const f32x2 v = {x, y};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+__device__ __forceinline__ void split4(const float v[4], u32x2& h, u32x2& m, u32x2& l) {
+    h.x = pk_bf16(v[0], v[1]);
+    h.y = pk_bf16(v[2], v[3]);
+    const float r0 = v[0] - bf_lo(h.x), r1 = v[1] - bf_hi(h.x), r2 = v[2] - bf_lo(h.y), r3 = v[3] - bf_hi(h.y);
+    m.x = pk_bf16(r0, r1);
+    m.y = pk_bf16(r2, r3);
+    l.x = pk_bf16(r0 - bf_lo(m.x), r1 - bf_hi(m.x));
+    l.y = pk_bf16(r2 - bf_lo(m.y), r3 - bf_hi(m.y));
+}
+__device__ __forceinline__ void glds16(const uint4* g, uint4* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+// 16-byte write-through store (sc1): the bytes are in memory, not in this XCD's L2, once vmcnt has counted it
+__device__ __forceinline__ void store16_sc1(uint4* p, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+// lanes L (even 16-lane row) and L + 16 (odd row) hold halves (a, b) of two different chunks; afterwards the even row
+// holds both halves of its chunk in (a, b) and the odd row both halves of its own: v_permlane16_swap exchanges the
+// odd rows of the first operand with the even rows of the second
+__device__ __forceinline__ void pair_swap(u32x2& a, u32x2& b) {
+    const u32x2 r0 = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+    const u32x2 r1 = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+    a = u32x2{r0.x, r1.x};
+    b = u32x2{r0.y, r1.y};
+}
+__device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct Item { int q, idx; };
+
+// queue q holds the row blocks q, q + 8, ...: nq of them, all layers
+__device__ __forceinline__ int queue_blocks(int q, int tiles_m) { return q < tiles_m ? (tiles_m - q + 7) >> 3 : 0; }
+
+// tab = {cum[0 .. kMaxLayers], tiles_n[0 .. kMaxLayers - 1]} in LDS: indexed by values that live in vector registers
+// (thread 0's successor bookkeeping), where an index into the kernel arguments would be a blocking global load
+__device__ __forceinline__ void decode(const int* tab, int n_layers, int tiles_m, int q, int idx, int& l, int& rb, int& tn) {
+    const int nq = queue_blocks(q, tiles_m);
+    l = 0;
+    while (l + 1 < n_layers && idx >= nq * tab[l + 1]) ++l;
+    const int rem = idx - nq * tab[l];
+    const int tnn = tab[kMaxLayers + 1 + l];
+    const int j = rem / tnn;
+    tn = rem - j * tnn;
+    rb = q + 8 * j;
+}
+
+// one lane: the counter of (layer l - 1, row block rb) has reached that layer's tile count, or the launch has failed
+__device__ __forceinline__ bool dep_ready(const ChainArgs& P, const int* tab, int l, int rb) {
+    if (l == 0) return true;
+    return ld_agent(P.ws + WS_DONE + (l - 1) * P.tiles_m + rb) >= (unsigned)tab[kMaxLayers + l];
+}
+
+__global__ __launch_bounds__(256) void mlp_chain(const ChainArgs P) {
+    __shared__ uint4 lds[CH_BUF];
+    __shared__ int nxt_s[8];                                  // successor: {queue, index, ready, layer, row block, column tile}
+    __shared__ int tab[2 * kMaxLayers + 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int a_off = kq * 128 + wr * 64 + r16, w_off = CH_A + kq * BNT + wc * 32 + r16;
+    unsigned* const ws = P.ws;
+    const int M = P.M, tiles_m = P.tiles_m;
+    // HW_REG_XCC_ID (id 20), bits 3:0: the XCD this workgroup runs on; locality only, never correctness
+    const int my_xcd = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u);
+
+    if (threadIdx.x <= kMaxLayers) tab[threadIdx.x] = P.cum[threadIdx.x < (unsigned)P.n_layers ? threadIdx.x : P.n_layers];
+    if (threadIdx.x < kMaxLayers) tab[kMaxLayers + 1 + threadIdx.x] = threadIdx.x < (unsigned)P.n_layers ? P.L[threadIdx.x].tiles_n : 1;
+    __syncthreads();
+    // ---- thread 0's private scheduling state ----
+    int curq = my_xcd, tried = 0;                             // queue being pulled from, queues found empty so far
+    const int items_per_block = P.cum[P.n_layers];
+    auto qlen = [&](int q) { return queue_blocks(q, tiles_m) * items_per_block; };
+    // blocking pull (start of the launch, end of a queue): next item of the first non-empty queue from curq on
+    auto pull_blocking = [&]() -> Item {
+        unsigned head[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) head[k] = ld_agent(ws + k * 32);     // eight loads in flight: one round trip
+        while (tried < 8) {
+            const int n = qlen(curq);
+            unsigned hq = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) hq = k == curq ? head[k] : hq;
+            if (n > 0 && hq < (unsigned)n) {
+                const int idx = (int)__hip_atomic_fetch_add(ws + curq * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (idx < n) return Item{curq, idx};
+            }
+            curq = (curq + 1) & 7;
+            ++tried;
+        }
+        return Item{-1, -1};
+    };
+    // blocking wait for an item's dependency, then the agent acquire
+    auto wait_dep = [&](int l, int rb) {
+        if (l == 0) return;
+        const uint64_t t0 = wall_clock64();
+        while (!dep_ready(P, tab, l, rb)) {
+            if (ld_agent(ws + WS_FAIL)) break;
+            if (wall_clock64() - t0 > kTimeoutTicks) {
+                __hip_atomic_store(ws + WS_FAIL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    if (P.delay_ticks > 0 && (blockIdx.x >= gridDim.x / 2)) {   // optional stagger of the second workgroup of a CU
+        const uint64_t t0 = wall_clock64();
+        while (wall_clock64() - t0 < (uint64_t)P.delay_ticks) __builtin_amdgcn_s_sleep(16);
+    }
+
+#define HD_STAMP(k) if (P.dbg && tid == 0) P.dbg[blockIdx.x * 8 + (k)] = wall_clock64();
+    HD_STAMP(0)
+    // ---- first item ----
+    if (tid == 0) {
+        const Item it = pull_blocking();
+        if (it.q >= 0) {
+            int l, rb, tn;
+            decode(tab, P.n_layers, tiles_m, it.q, it.idx, l, rb, tn);
+            wait_dep(l, rb);
+        }
+        nxt_s[0] = it.q; nxt_s[1] = it.idx; nxt_s[2] = 1;
+    }
+    __syncthreads();
+    int cq = __builtin_amdgcn_readfirstlane(nxt_s[0]), cidx = __builtin_amdgcn_readfirstlane(nxt_s[1]);
+    int seq = 0;                                              // tiles this workgroup has finished (debugging)
+    (void)seq;
+    int done_l = -1, done_rb = 0;                             // finished tile whose counter add is still owed
+
+#define HD_STAGE(as_, ws_, t)                                                               \
+    {                                                                                       \
+        const uint4* as = (as_) + (size_t)(t) * kTile;                                      \
+        const uint4* wsrc = (ws_) + (size_t)(t) * kTile;                                    \
+        _Pragma("unroll") for (int q = 0; q < QA; ++q) {                                    \
+            const int piece = q * 4 + wave;                                                 \
+            glds16(as + piece * 64, lds + piece * 64);                                      \
+        }                                                                                   \
+        _Pragma("unroll") for (int q = 0; q < QW; ++q) {                                    \
+            const int piece = q * 4 + wave;                                                 \
+            glds16(wsrc + piece * 128, lds + CH_A + piece * 64);                            \
+        }                                                                                   \
+    }
+    auto a_src = [&](int l, int rb) {
+        const uint4* base = l == 0 ? P.A0 : P.L[l - 1].out_img;
+        return base + (size_t)rb * P.L[l].nslab * kTile + lane;
+    };
+    auto w_src = [&](int l, int tn) { return P.L[l].W + (size_t)(tn >> 1) * P.L[l].nslab * kTile + (tn & 1) * 64 + lane; };
+
+    HD_STAMP(1)
+    int stamped = 0;
+    if (cq >= 0) {
+        int l, rb, tn;
+        decode(tab, P.n_layers, tiles_m, cq, cidx, l, rb, tn);
+        l = __builtin_amdgcn_readfirstlane(l); rb = __builtin_amdgcn_readfirstlane(rb); tn = __builtin_amdgcn_readfirstlane(tn);
+        const uint4 *a_cur = a_src(l, rb), *w_cur = w_src(l, tn);
+        HD_STAGE(a_cur, w_cur, 0)
+        for (;;) {
+            const Layer& Ly = P.L[l];
+            const int nslab = Ly.nslab;
+            const unsigned long long tile_t0 = P.dbg ? wall_clock64() : 0ull;
+            f32x4 acc[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+            // successor, fetched asynchronously by thread 0 while this tile multiplies (nslab >= 4)
+            // thread 0 only.  `pend` is the ONE register that receives what the op issued in the previous slab returns;
+            // it is read at the start of the next slab's step, after the vmcnt(0) at the top of that slab, so the compiler
+            // never has a reason to wait for it where it is issued.
+            int p_idx = -1, p_l = 0, p_rb = 0, p_tn = 0, p_ready = 0, p_state = 0;   // 1 pull issued, 2 pulled, 3 poll issued
+            unsigned pend = 0;
+            int nq_ = -1, nidx_ = -1, nready_ = 0, nl_ = 0, nrb_ = 0, ntn_ = 0;   // every thread, after the hand-over slab
+            // pull, decode, poll, acquire, hand-over in the LAST five slabs: an item is reserved only a few microseconds
+            // before it starts, so the launch does not end on workgroups that sit on a reserved tile while others are idle
+            const bool async = nslab >= 5 && !(P.flags & 4);
+            const int t_poll = nslab - 3, t_pull = nslab - 5;
+            const uint4 *a_n = nullptr, *w_n = nullptr;
+            for (int t = 0; t < nslab; ++t) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (async && t == t_poll + 2 && tid == 0) {    // hand the successor to the other wavefronts
+                    nxt_s[0] = curq; nxt_s[1] = p_idx; nxt_s[2] = p_ready; nxt_s[3] = p_l; nxt_s[4] = p_rb; nxt_s[5] = p_tn;
+                }
+                __builtin_amdgcn_s_barrier();                   // slab t has landed; every wave's older stores are done
+                uint4 fa[4][3], fw[2][3];
+#pragma unroll
+                for (int li = 0; li < 3; ++li) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fa[i][li] = lds[a_off + li * 4 * 128 + i * 16];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) fw[j][li] = lds[w_off + li * 4 * BNT + j * 16];
+                }
+                if (async && t == t_poll + 2) {
+                    nq_ = __builtin_amdgcn_readfirstlane(nxt_s[0]);
+                    nidx_ = __builtin_amdgcn_readfirstlane(nxt_s[1]);
+                    nready_ = __builtin_amdgcn_readfirstlane(nxt_s[2]);
+                    nl_ = __builtin_amdgcn_readfirstlane(nxt_s[3]);
+                    nrb_ = __builtin_amdgcn_readfirstlane(nxt_s[4]);
+                    ntn_ = __builtin_amdgcn_readfirstlane(nxt_s[5]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                   // every wave holds its fragments: the buffer is free
+                // Thread 0's step of the successor protocol, on the four slabs that have one (a scalar test elsewhere).
+                // Nothing may sit between the vmcnt(0) at the top of a slab and its fragment reads, and nothing may delay
+                // this slab's staging loads: the value the previous step left in flight is taken over (one move, after
+                // which the compiler has no reason to wait again), the loads go out, and only then does the step run --
+                // under the loads' latency -- and issue its own operation behind them.
+                const bool act = async && (t == t_pull || t == t_pull + 1 || t == t_poll || t == t_poll + 1);
+                unsigned got = 0;
+                if (act && tid == 0) asm volatile("v_mov_b32 %0, %1" : "=v"(got) : "v"(pend));
+                if (t + 1 < nslab) {
+                    HD_STAGE(a_cur, w_cur, t + 1)
+                } else if (nidx_ >= 0 && nready_) {
+                    a_n = a_src(nl_, nrb_); w_n = w_src(nl_, ntn_);
+                    HD_STAGE(a_n, w_n, 0)
+                }
+                if (t == 0 && done_l >= 0) {
+                    // the previous tile's image stores were complete in every wavefront at this slab's first barrier (each
+                    // waited vmcnt(0) before it): raise its row block's counter
+                    if (tid == 0)
+                        __hip_atomic_fetch_add(ws + WS_DONE + done_l * tiles_m + done_rb, 1u, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                    done_l = -1;
+                }
+                if (act && tid == 0) {
+                    unsigned* addr = nullptr;
+                    unsigned inc = 0;
+                    if (t == t_pull) {
+                        if (tried < 8 && qlen(curq) > 0) { addr = ws + curq * 32; inc = 1; p_state = 1; }
+                    } else if (t == t_pull + 1) {
+                        if (p_state == 1 && got < (unsigned)qlen(curq)) {
+                            p_idx = (int)got;
+                            decode(tab, P.n_layers, tiles_m, curq, p_idx, p_l, p_rb, p_tn);
+                            p_state = 2;
+                        }
+                    } else if (t == t_poll) {
+                        if (p_state == 2) {
+                            if (p_l == 0) p_ready = 1;
+                            else { addr = ws + WS_DONE + (p_l - 1) * tiles_m + p_rb; p_state = 3; }   // poll = add 0
+                        }
+                    } else {
+                        if (p_state == 3 && got >= (unsigned)tab[kMaxLayers + p_l]) {
+                            p_ready = 1;
+                            // agent acquire for the successor's A operand: invalidate this CU's L1; the vmcnt(0) at the top of
+                            // the next slab waits for it, the barrier behind that orders the other wavefronts' loads
+                            asm volatile("buffer_inv sc1" ::: "memory");
+                        }
+                    }
+                    if (addr) pend = __hip_atomic_fetch_add(addr, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4 c = acc[i][j];
+#define HD_MM(wl, al) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[j][wl]), \
+                                                                  __builtin_bit_cast(bf16x8, fa[i][al]), c, 0, 0, 0);
+                        HD_MM(0, 2) HD_MM(2, 0) HD_MM(1, 1) HD_MM(0, 1) HD_MM(1, 0) HD_MM(0, 0)
+#undef HD_MM
+                        acc[i][j] = c;
+                    }
+            }
+            if (!stamped) HD_STAMP(2)
+            if (P.dbg && tid == 0 && seq < 24) {
+                unsigned long long* e = P.dbg + 512 * 8 + ((size_t)blockIdx.x * 24 + seq) * 4;
+                e[0] = tile_t0; e[1] = wall_clock64(); e[3] = ((unsigned long long)l << 32) | ((unsigned)rb << 8) | (unsigned)tn;
+            }
+            // ---- write-out of the C^T tile: a lane owns row m and columns nb .. nb + 3 of accumulator (i, j) ----
+            {
+                const int m0 = rb * 128, n0 = tn * BNT + wc * 32;
+                const int N = Ly.N, epi = Ly.epi, ldc = Ly.ldc;
+                const float* __restrict__ bias = Ly.bias;
+                uint4* __restrict__ CL = Ly.out_img;
+                float* __restrict__ C = Ly.out_f32;
+                const bool vec = (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+                float bq[2][4];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int n = n0 + j * 16 + 4 * kq + e;
+                        bq[j][e] = (bias && n < N) ? bias[n] : 0.f;
+                    }
+                // the wavefront's 32 columns are exactly K slab `so` of the output image
+                const int so = n0 >> 5;
+                const bool img = CL != nullptr && so < Ly.nslab_out;
+                // this lane's chunk after the pair swap: even 16-lane rows keep accumulator j = 0 (chunk kc = kq / 2),
+                // odd rows j = 1 (kc = 2 + kq / 2)
+                const int kc_mine = (kq & 1) * 2 + (kq >> 1);
+                uint4* const cl_base = img ? CL + ((size_t)rb * Ly.nslab_out + so) * kTile + kc_mine * 128 : nullptr;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int mloc = wr * 64 + i * 16 + r16;
+                    const int m = m0 + mloc;
+                    const bool row_ok = m < M;
+                    float v[2][4];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float x = acc[i][j][e] + bq[j][e];
+                            if (epi == 1) x = gelu_erfc(x);
+                            // columns past N are the zero padding of the next layer's K; rows past M are written as zeros
+                            v[j][e] = (row_ok && n0 + j * 16 + 4 * kq + e < N) ? x : 0.f;
+                        }
+                    if (img) {
+                        u32x2 h0, m0_, l0, h1, m1, l1;
+                        split4(v[0], h0, m0_, l0);
+                        split4(v[1], h1, m1, l1);
+                        pair_swap(h0, h1);
+                        pair_swap(m0_, m1);
+                        pair_swap(l0, l1);
+                        // even rows now hold {own j = 0 half, partner's j = 0 half} in (x0, x1); odd rows {partner's j = 1
+                        // half, own j = 1 half}: in both cases (first, second) = columns (8 kc .. + 3, + 4 .. + 7)
+                        uint4* o = cl_base + mloc;
+                        store16_sc1(o, u32x4{h0.x, h0.y, h1.x, h1.y});
+                        store16_sc1(o + 4 * 128, u32x4{m0_.x, m0_.y, m1.x, m1.y});
+                        store16_sc1(o + 8 * 128, u32x4{l0.x, l0.y, l1.x, l1.y});
+                    }
+                    if (C && row_ok) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int nb = n0 + j * 16 + 4 * kq;
+                            float* o = C + (size_t)m * ldc + nb;
+                            if (vec && nb + 3 < N) {
+                                // write-through as well: nothing of this launch is left dirty in the L2s when it ends
+                                store16_sc1(reinterpret_cast<uint4*>(o), __builtin_bit_cast(u32x4, f32x4{v[j][0], v[j][1], v[j][2], v[j][3]}));
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (nb + e < N) o[e] = v[j][e];
+                            }
+                        }
+                    }
+                }
+            }
+            if (!stamped) { HD_STAMP(3) stamped = 1; }
+            if (P.dbg && tid == 0 && seq < 24) P.dbg[512 * 8 + ((size_t)blockIdx.x * 24 + seq) * 4 + 2] = wall_clock64();
+            ++seq;
+            done_l = (l + 1 < P.n_layers) ? l : -1;            // the last layer feeds nobody
+            done_rb = rb;
+            if (async && nidx_ >= 0 && nready_) {               // successor already streaming into LDS
+                cq = nq_; cidx = nidx_;
+                l = nl_; rb = nrb_; tn = ntn_;
+                a_cur = a_n; w_cur = w_n;
+                continue;
+            } else {
+                // slow path: end of a queue, a dependency that was not ready at the poll, or a tile of < 4 slabs
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    if (done_l >= 0)
+                        __hip_atomic_fetch_add(ws + WS_DONE + done_l * tiles_m + done_rb, 1u, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                    if (P.flags & 8) {
+                        atomicAdd(ws + WS_STAT, 1u);
+                        if (async && p_idx >= 0) atomicAdd(ws + WS_STAT + 1, 1u);
+                        if (async && p_state == 0) atomicAdd(ws + WS_STAT + 2, 1u);
+                    }
+                    Item it;
+                    if (async && p_idx >= 0) it = Item{curq, p_idx};          // pulled, its dependency was not ready
+                    else it = pull_blocking();
+                    if (it.q >= 0) {
+                        int l2, rb2, tn2;
+                        decode(tab, P.n_layers, tiles_m, it.q, it.idx, l2, rb2, tn2);
+                        wait_dep(l2, rb2);
+                    }
+                    nxt_s[0] = it.q; nxt_s[1] = it.idx; nxt_s[2] = 1;
+                }
+                done_l = -1;
+                __syncthreads();
+                cq = __builtin_amdgcn_readfirstlane(nxt_s[0]);
+                cidx = __builtin_amdgcn_readfirstlane(nxt_s[1]);
+                if (cq < 0) break;
+                decode(tab, P.n_layers, tiles_m, cq, cidx, l, rb, tn);
+                l = __builtin_amdgcn_readfirstlane(l); rb = __builtin_amdgcn_readfirstlane(rb);
+                tn = __builtin_amdgcn_readfirstlane(tn);
+                a_cur = a_src(l, rb); w_cur = w_src(l, tn);
+                HD_STAGE(a_cur, w_cur, 0)
+                continue;
+            }
+        }
+    }
+#undef HD_STAGE
+    // ---- leave: the last workgroup out cleans the workspace for the next launch (and reports a failed one) ----
+    HD_STAMP(4)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    HD_STAMP(5)
+    if (tid == 0) {
+        // last one out, found in two levels (512 adds to one word are ~6 us of serialised atomics when the workgroups
+        // finish together): eight groups by blockIdx, the last of a group adds to the top word
+        const unsigned g = blockIdx.x & 7u, gsize = (gridDim.x - g + 7u) >> 3;
+        unsigned last = 0;
+        if (__hip_atomic_fetch_add(ws + WS_EXIT_GROUP + g * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
+            const unsigned groups = gridDim.x < 8u ? gridDim.x : 8u;
+            last = __hip_atomic_fetch_add(ws + WS_EXITED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1;
+        }
+        nxt_s[0] = (int)last;
+        nxt_s[1] = (int)ld_agent(ws + WS_FAIL);
+    }
+    __syncthreads();
+    HD_STAMP(6)
+    if (P.dbg && tid == 0) P.dbg[blockIdx.x * 8 + 7] = ((unsigned long long)seq << 8) | (unsigned)my_xcd;
+    if (nxt_s[0]) {
+        const int words = WS_DONE + (P.n_layers > 1 ? (P.n_layers - 1) * tiles_m : 0);
+        for (int i = tid; i < words; i += 256)
+            if (i != WS_FAIL && !(i >= WS_STAT && i < WS_STAT + 4)) __hip_atomic_store(ws + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nxt_s[1]) {                                         // a wait timed out somewhere: make the failure loud
+            const Layer& Lz = P.L[P.n_layers - 1];
+            if (Lz.out_f32)
+                for (size_t i = tid; i < (size_t)M * Lz.ldc; i += 256)
+                    if ((int)(i % Lz.ldc) < Lz.N) Lz.out_f32[i] = __builtin_nanf("");
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t hd_mlp_chain_workspace_bytes(int64_t rows, int n_layers) {
+    if (rows < 0 || n_layers < 1 || n_layers > kMaxLayers) return -1;
+    const int64_t tiles_m = (rows + 127) / 128;
+    return (WS_DONE + (int64_t)(n_layers - 1) * tiles_m) * 4 + 256;
+}
+
+extern "C" int hd_mlp_chain_limbs_f32(const void* A0, int64_t rows, const hd_mlp_chain_layer* layers, int n_layers,
+                                      void* workspace, int64_t workspace_bytes, void* st) {
+    HD_REQUIRE(n_layers >= 1 && n_layers <= kMaxLayers && layers, "hd_mlp_chain_limbs_f32: between 1 and %d layers", kMaxLayers);
+    HD_REQUIRE(rows >= 0 && rows < (1LL << 31), "hd_mlp_chain_limbs_f32: bad row count");
+    if (rows == 0) return HD_OK;
+    HD_REQUIRE(A0 && is_aligned16(A0) && workspace && is_aligned16(workspace), "hd_mlp_chain_limbs_f32: null or misaligned pointer");
+    HD_REQUIRE(workspace_bytes >= hd_mlp_chain_workspace_bytes(rows, n_layers), "hd_mlp_chain_limbs_f32: workspace too small");
+    ChainArgs P{};
+    P.A0 = (const uint4*)A0;
+    P.ws = (unsigned*)workspace;
+    P.n_layers = n_layers;
+    P.M = (int)rows;
+    P.tiles_m = (int)((rows + 127) / 128);
+    int64_t items = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        const hd_mlp_chain_layer& s = layers[i];
+        HD_REQUIRE(s.N >= 1 && s.K >= 1 && s.N < (1LL << 31) && s.K < (1LL << 31), "hd_mlp_chain_limbs_f32: layer %d: bad shape", i);
+        HD_REQUIRE(i == 0 || s.K == layers[i - 1].N, "hd_mlp_chain_limbs_f32: layer %d: K = %lld but layer %d has N = %lld", i,
+                   (long long)s.K, i - 1, (long long)layers[i - 1].N);
+        HD_REQUIRE(s.W && is_aligned16(s.W), "hd_mlp_chain_limbs_f32: layer %d: null or misaligned weight image", i);
+        HD_REQUIRE(s.epi == 0 || s.epi == 1, "hd_mlp_chain_limbs_f32: layer %d: epilogue must be 0 (none) or 1 (GELU)", i);
+        const bool last = i == n_layers - 1;
+        HD_REQUIRE(last || (s.out_image && is_aligned16(s.out_image)),
+                   "hd_mlp_chain_limbs_f32: layer %d: an inner layer needs a (16-byte aligned) output image", i);
+        HD_REQUIRE(!last || s.out_f32 || s.out_image, "hd_mlp_chain_limbs_f32: the last layer needs an output");
+        HD_REQUIRE(!s.out_f32 || s.ldc >= s.N, "hd_mlp_chain_limbs_f32: layer %d: leading dimension too small", i);
+        HD_REQUIRE((int64_t)rows * (s.out_f32 ? s.ldc : 1) < (1LL << 40), "hd_mlp_chain_limbs_f32: output too large");
+        Layer& L = P.L[i];
+        L.W = (const uint4*)s.W;
+        L.bias = (const float*)s.bias;
+        L.out_img = (uint4*)s.out_image;
+        L.out_f32 = (float*)s.out_f32;
+        L.N = (int)s.N;
+        L.nslab = (int)((s.K + 31) / 32);
+        L.tiles_n = (int)((s.N + BNT - 1) / BNT);
+        L.nslab_out = (int)((s.N + 31) / 32);
+        L.epi = s.epi;
+        L.ldc = (int)(s.out_f32 ? s.ldc : s.N);
+        P.cum[i] = (int)items;
+        items += L.tiles_n;
+    }
+    P.cum[n_layers] = (int)items;
+    HD_REQUIRE(items * ((P.tiles_m + 7) / 8) < (1LL << 30), "hd_mlp_chain_limbs_f32: too many tiles");
+    struct Knobs { int n_cu, delay_ns, flags, reload, per_cu; };
+    static Knobs knobs = [] {
+        Knobs k{256, 0, 0, 0, 2};
+        if (const char* e = getenv("HD_MLP_CHAIN_PER_CU")) k.per_cu = atoi(e);
+        if (const char* e = getenv("HD_MLP_CHAIN_DELAY_NS")) k.delay_ns = atoi(e);
+        if (const char* e = getenv("HD_MLP_CHAIN_FLAGS")) k.flags = atoi(e);
+        if (const char* e = getenv("HD_GEMM_TUNE_RELOAD")) k.reload = atoi(e);
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            k.n_cu = prop.multiProcessorCount;
+        return k;
+    }();
+    if (knobs.reload) {
+        if (const char* e = getenv("HD_MLP_CHAIN_DELAY_NS")) knobs.delay_ns = atoi(e);
+        if (const char* e = getenv("HD_MLP_CHAIN_FLAGS")) knobs.flags = atoi(e);
+        if (const char* e = getenv("HD_MLP_CHAIN_PER_CU")) knobs.per_cu = atoi(e);
+    }
+    P.delay_ticks = knobs.delay_ns / 10;
+    P.flags = knobs.flags;
+    P.dbg = nullptr;
+    if (knobs.reload)
+        if (const char* e = getenv("HD_MLP_CHAIN_DEBUG_PTR")) P.dbg = (unsigned long long*)strtoull(e, nullptr, 0);
+    const int64_t total = items * P.tiles_m;
+    // The kernel's registers (166) and LDS (36 KB) would admit three workgroups per CU; a grid of two per CU is then
+    // NOT spread evenly by the dispatcher (some CUs get three, others one).  Unused dynamic LDS pads the footprint so
+    // that exactly `per_cu` workgroups fit a CU (160 KB) and the grid fills the chip evenly.
+    const int per_cu = knobs.per_cu >= 1 && knobs.per_cu <= 3 ? knobs.per_cu : 2;
+    int64_t grid = (int64_t)knobs.n_cu * per_cu / 8 * 8;
+    if (grid < 8) grid = 8;
+    if (grid > total) grid = total;
+    const size_t static_lds = CH_BUF * 16 + 64;
+    const size_t want = per_cu == 3 ? 0 : (per_cu == 2 ? 56 * 1024 : 100 * 1024);
+    const size_t pad = want > static_lds ? want - static_lds : 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                100 * 1024) != hipSuccess) {
+            set_error("hd_mlp_chain_limbs_f32: hipFuncSetAttribute failed");
+            return HD_EHIP;
+        }
+        attr_set = true;
+    }
+    mlp_chain<<<dim3((unsigned)grid), dim3(256), pad, (hipStream_t)st>>>(P);
+    return check_launch("hd_mlp_chain_limbs_f32");
+}
+
+// 1 if a wait of any launch on this workspace timed out since the last query (the fp32 output of that launch is NaN);
+// clears the flag.  Synchronises the stream.
+extern "C" int hd_mlp_chain_failed(void* workspace, void* st) {
+    if (!workspace) return 0;
+    unsigned flag = 0;
+    if (hipMemcpyAsync(&flag, (unsigned*)workspace + WS_FAIL, 4, hipMemcpyDeviceToHost, (hipStream_t)st) != hipSuccess) return -1;
+    if (hipStreamSynchronize((hipStream_t)st) != hipSuccess) return -1;
+    if (flag) {
+        if (hipMemsetAsync((unsigned*)workspace + WS_FAIL, 0, 4, (hipStream_t)st) != hipSuccess) return -1;
+    }
+    return flag ? 1 : 0;
+}

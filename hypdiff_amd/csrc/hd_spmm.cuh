@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void spmm_long(const int32_t* __re
 template <class M, typename T>
 int launch_spmm(const char* name, const int32_t* rowptr, const int32_t* col, const void* val, const void* x,
                 void* out, int64_t n, int64_t d, int epi, hd_curv ci, hd_curv co, int act,
-                const int32_t* long_rows, int64_t n_long, void* st, int64_t ldx = 0, int64_t ldo = 0) {
+                const int32_t* long_rows, int64_t n_long, void* st, int64_t ldx = 0, int64_t ldo = 0, int form = 0) {
     HD_REQUIRE(n >= 0 && d >= 1, "%s: bad shape rows=%lld dim=%lld", name, (long long)n, (long long)d);
     if (ldx == 0) ldx = d;                              // row pitches (elements); 0 = contiguous rows
     if (ldo == 0) ldo = d;
@@ -262,7 +262,12 @@ int launch_spmm(const char* name, const int32_t* rowptr, const int32_t* col, con
     // adjacencies without long rows; on the ball it won on both, 2.72 -> 2.69 ms and 29.5 -> 20.5 us)
     // (and only when there are rows enough to keep every SIMD busy with four-row tasks: a 2708-row graph ran its
     // aggregate 45 us in the four-row form against 20 us one row per wavefront -- latency-bound, not chain-bound)
-    const int row_flags = (n_long > 0 ? 1 : 0) | ((rows4 && n >= 8192 && (!IsHB<M>::value || n_long == 0)) ? 2 : 0);
+    // The two forms of the fused tail differ by rounding, so WHICH one runs is a property of the adjacency, not of the
+    // launch: `form` 1 (one row per wavefront) / 2 (four rows) pins it -- a row shard passes the form the unsharded
+    // graph takes (hypdiff_amd/dist.py) -- and 0 decides from this launch's own rows.
+    HD_REQUIRE(form >= 0 && form <= 2, "%s: form must be 0 (auto), 1 or 2", name);
+    const bool four = form == 2 || (form == 0 && rows4 && n >= 8192 && (!IsHB<M>::value || n_long == 0));
+    const int row_flags = (n_long > 0 ? 1 : 0) | (four ? 2 : 0);
     int rc = dispatch_cfg<T>(c, [&](auto g, auto v) {
         constexpr int G = decltype(g)::value, V = decltype(v)::value;
         constexpr int R0 = V < 4 ? 4 : V;              // smallest specialisation
@@ -323,14 +328,14 @@ int launch_spmm(const char* name, const int32_t* rowptr, const int32_t* col, con
                                    hd_curv c_out, int act, int fuse_act, const int32_t* long_rows,         \
                                    int64_t n_long, void* st) {                                             \
         return hd::launch_spmm<hd::PB<T>, T>("hd_pb_agg_" #sfx, rowptr, col, val, xt, out, n, d,          \
-                                             fuse_act ? hd::E_AGG_ACT : hd::E_AGG, c_in, c_out, act,       \
-                                             long_rows, n_long, st);                                       \
+                                             (fuse_act & 1) ? hd::E_AGG_ACT : hd::E_AGG, c_in, c_out, act, \
+                                             long_rows, n_long, st, 0, 0, (fuse_act >> 8) & 3);            \
     }                                                                                                      \
     extern "C" int hd_hb_agg_##sfx(const int32_t* rowptr, const int32_t* col, const void* val,            \
                                    const void* xt, void* out, int64_t n, int64_t d, hd_curv c_in,          \
                                    hd_curv c_out, int act, int fuse_act, const int32_t* long_rows,         \
                                    int64_t n_long, void* st) {                                             \
         return hd::launch_spmm<hd::HB<T>, T>("hd_hb_agg_" #sfx, rowptr, col, val, xt, out, n, d,          \
-                                             fuse_act ? hd::E_AGG_ACT : hd::E_AGG, c_in, c_out, act,       \
-                                             long_rows, n_long, st);                                       \
+                                             (fuse_act & 1) ? hd::E_AGG_ACT : hd::E_AGG, c_in, c_out, act, \
+                                             long_rows, n_long, st, 0, 0, (fuse_act >> 8) & 3);            \
     }

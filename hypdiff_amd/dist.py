@@ -326,6 +326,10 @@ class RowShardedAdj:
         self.local_indices = np.vstack((indices[0, a:b] - self.lo, indices[1, a:b])).astype(np.int64)
         self.local_values = values[a:b]
         self.local_shape = (self.rows_per_rank, self.rows_per_rank * world_size)
+        # rows of the WHOLE graph above the SpMM's long-row threshold: the fused aggregate tail has two forms that
+        # differ by rounding and picks by (rows, long rows); every shard runs the form the whole graph takes
+        deg = np.bincount(indices[0].astype(np.int64), minlength=n) if indices.shape[1] else np.zeros(n, np.int64)
+        self.n_long_whole = int((deg > 512).sum())
 
     def _padded(self, x_local):
         if x_local.shape[0] == self.rows_per_rank:
@@ -373,7 +377,7 @@ class RowShardedAdj:
         """HypAgg's support_t for the local rows: all-gather the tangent block, then
         spmm(local_adj, gathered).  `spmm(indices, values, shape, x)` is the device SpMM
         (ops.spmm on a CSR of the local block) -- injected so that the CPU tests can pass a
-        host implementation.  Summation order per row is unchanged -> bit-identical to 1 GPU."""
+        host implementation.  Summation order per row is unchanged -> the support rows are bit-identical to 1 GPU."""
         full = self.gather_rows(xt_local, group)
         out = spmm(self.local_indices, self.local_values, self.local_shape, full)
         return out[: self.hi - self.lo]
@@ -401,9 +405,13 @@ def sharded_hgcn_encode(encoder, x_local, sharded_adj, group=None, n_slabs=4):
                      expmap0 / proj / HypAct on the assembled rows (hd_*_agg_tail)
 
     With one slab (or a world of one rank) the aggregate is the single fused kernel of the 1-GPU
-    path.  `x_local` holds this rank's rows of the features (Hyperboloid: zero time column already
-    prepended).  Per row and feature the summation order is that of the 1-GPU kernel, so the result
-    is bit-identical to encoder.encode on the whole graph.  Inference path (torch.no_grad())."""
+    path, in the form (one or four rows per wavefront: ops.agg_form) that the WHOLE graph takes, so the
+    result is bit-identical to encoder.encode on the whole graph.  `x_local` holds this rank's rows of
+    the features (Hyperboloid: zero time column already prepended).  Per row and feature the summation
+    order is that of the 1-GPU kernel.  The slab-pipelined path finishes the rows with hd_*_agg_tail,
+    which evaluates the tail in the one-row form: bit-identical to the 1-GPU encode where that takes the
+    one-row form too (fewer than 8192 rows, or a Hyperboloid graph with long rows), within a few ulp
+    (2e-6 relative) of it otherwise.  Inference path (torch.no_grad())."""
     from .models.encoders import _lift
     n_loc = sharded_adj.hi - sharded_adj.lo
     assert x_local.shape[0] == n_loc, (x_local.shape, n_loc)
@@ -426,6 +434,8 @@ def shard_csr(sharded_adj, device):
         sharded_adj._csr = ops.csr_from_coo(torch.from_numpy(sharded_adj.local_indices).to(device),
                                             torch.from_numpy(np.ascontiguousarray(sharded_adj.local_values)).to(device),
                                             sharded_adj.local_shape)
+        assert ops.CSR.LONG_ROW == 512
+        sharded_adj._csr.whole = (sharded_adj.n, sharded_adj.n_long_whole)
     return sharded_adj._csr
 
 

@@ -496,6 +496,8 @@ def linear_chain(x, layers):
         fmt = "f16x2" if GEMM_MODE == "f16x2" and all(epi in (0, 1) for _, _, epi in layers) else "bf16x3"
         a, xf = limb_pack(x, fmt), x
     # f16x2: the row exponents / maxima of every intermediate image in one zero-filled allocation
+    if fmt == "bf16x3" and mlp_chain_ok(a, layers):
+        return mlp_chain(a, layers)
     sc = torch.zeros(len(layers) - 1, 2, max(a.rows, 1), dtype=torch.int32, device=a.buf.device) \
         if fmt == "f16x2" and len(layers) > 1 else None
     for i, (w, b, epi) in enumerate(layers):
@@ -510,6 +512,71 @@ def linear_chain(x, layers):
                            bias_max=_bias_absmax(b) if fmt == "f16x2" and not last else None,
                            out_scales=sc[i] if sc is not None and not last else None)
     return xf
+
+
+# ---- the whole stack as ONE persistent launch over many rows (csrc/gemm_chain.hip) ----
+MLP_CHAIN_MIN_ROWS = 4096                                     # below this the per-layer launches are not round-bound
+_NO_MLP_CHAIN = bool(os.environ.get("HD_NO_MLP_CHAIN"))       # A/B knob: one hd_gemm_limbs_f32 launch per layer
+_mlp_chain_ws = {}
+
+
+def mlp_chain_ok(a, layers):
+    """hd_mlp_chain_limbs_f32 applies: bf16x3 image input, 2..8 layers with epilogues none / GELU only, enough rows."""
+    return (not _NO_MLP_CHAIN and isinstance(a, LimbImage) and a.fmt == "bf16x3" and a.rows >= MLP_CHAIN_MIN_ROWS
+            and 2 <= len(layers) <= 8 and all(epi in (0, 1) for _, _, epi in layers)
+            and all(w.dtype == torch.float32 for w, _, _ in layers))
+
+
+def mlp_chain(a, layers, out=None):
+    """layers = [(weight, bias, epi), ...] over the limb image `a`: every layer's tiles in one launch, a row block
+    flows from layer to layer as soon as its own tiles are complete.  Bit-identical to the per-layer launches."""
+    dev = a.buf.device
+    M = a.rows
+    arr = (_lib.HdMlpChainLayer * len(layers))()
+    keep, k_in, flops, nbytes = [], a.cols, 0.0, 0.0
+    for i, (w, b, epi) in enumerate(layers):
+        last = i == len(layers) - 1
+        wl, _ = weight_limbs(w, "bf16x3")
+        assert wl.cols == k_in, (wl.cols, k_in)
+        bd = None if b is None else b.detach()
+        n = wl.rows
+        img = None if last else limb_empty(M, n, dev, "bf16x3")
+        c = None
+        if last:
+            c = out if out is not None else torch.empty(M, n, dtype=torch.float32, device=dev)
+        keep += [wl, bd, img, c]
+        arr[i] = _lib.HdMlpChainLayer(_p(wl.buf), _p(bd), _p(img.buf) if img is not None else None, _p(c), n, k_in,
+                                      c.stride(0) if c is not None else n, epi)
+        kp, npad = (k_in + 31) // 32 * 32, (n + 31) // 32 * 32
+        flops += 2.0 * M * n * k_in
+        nbytes += 6.0 * (M * kp + n * kp) + (4.0 * M * n if last else 6.0 * M * npad)
+        k_in = n
+    key = (dev.index, torch.cuda.current_stream().cuda_stream, (M + 127) // 128, len(layers))
+    ws = _mlp_chain_ws.get(key)
+    if ws is None:
+        # zero-filled once: the kernel leaves it clean for the next launch on this stream
+        if len(_mlp_chain_ws) > 64:
+            _mlp_chain_ws.clear()
+        ws = _mlp_chain_ws[key] = torch.zeros(_lib.load().hd_mlp_chain_workspace_bytes(M, len(layers)) // 4 + 4,
+                                              dtype=torch.int32, device=dev)
+    ev = GEMM_EVENTS
+    if ev is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.call("hd_mlp_chain_limbs_f32", _p(a.buf), M, arr, len(layers), _p(ws), ws.numel() * 4, _stream())
+    if ev is not None:
+        e1.record()
+        ev.append((e0, e1, flops, nbytes, "mlp_chain"))
+    return keep[-1]
+
+
+def mlp_chain_failed():
+    """True if a device-side wait of any hd_mlp_chain_limbs_f32 launch timed out since the last call (its output is
+    NaN); synchronises the streams that own a workspace.  Tests and debugging."""
+    bad = False
+    for (_, stream, _, _), ws in _mlp_chain_ws.items():
+        bad |= _lib.load().hd_mlp_chain_failed(_p(ws), ctypes.c_void_p(stream)) == 1
+    return bad
 
 
 CHAIN_SMALL_MAX_ROWS, CHAIN_SMALL_MAX_WIDTH = 512, 512
@@ -680,18 +747,30 @@ def agg_tail(manifold, s, c_in, c_out=None, act_code=None):
     return out
 
 
+AGG_FOUR_ROW_MIN = 8192          # csrc/hd_spmm.cuh: from this many rows the fused tail runs four rows per wavefront
+
+
+def agg_form(manifold, n_rows, n_long):
+    """The form of the fused aggregate tail that hd_*_agg picks by itself for an adjacency of n_rows rows with n_long
+    rows above CSR.LONG_ROW entries: 2 = four rows per wavefront, 1 = one row per wavefront (they differ by rounding)."""
+    return 2 if n_rows >= AGG_FOUR_ROW_MIN and (manifold != "hb" or n_long == 0) else 1
+
+
 def agg(manifold, csr, xt, c_in, c_out=None, act_code=None):
-    """proj(expmap0(spmm(adj, xt))) [+ HypAct when act_code is given], one kernel."""
+    """proj(expmap0(spmm(adj, xt))) [+ HypAct when act_code is given], one kernel.  A CSR that is a row shard of a
+    larger graph carries `whole` = (rows, long rows) of that graph and runs the form the whole graph takes."""
     _dev(xt)
     x2 = xt.contiguous()
     if csr.shape[1] != x2.shape[0]:
         raise ValueError(f"adjacency {csr.shape} does not match {tuple(x2.shape)} rows")
     out = torch.empty(csr.shape[0], x2.shape[1], dtype=x2.dtype, device=x2.device)
     fuse = act_code is not None
+    whole = getattr(csr, "whole", None)
+    form = agg_form(manifold, *whole) if whole is not None else 0
     _lib.call(f"hd_{manifold}_agg" + _sfx(x2), _p(csr.rowptr), _p(csr.col), _p(csr.values(x2.dtype)), _p(x2),
               _p(out), csr.shape[0], x2.shape[1], curv(c_in), curv(c_out if fuse else c_in),
-              act_code if fuse else 0, 1 if fuse else 0, _p(csr.long_rows) if csr.n_long else None, csr.n_long,
-              _stream())
+              act_code if fuse else 0, (1 if fuse else 0) | (form << 8), _p(csr.long_rows) if csr.n_long else None,
+              csr.n_long, _stream())
     return out
 
 

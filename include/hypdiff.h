@@ -213,7 +213,11 @@ HD_DECL2(hd_spmm_csr, const int32_t* rowptr, const int32_t* col, const void* val
 HD_DECL2(hd_spmm_csr_strided, const int32_t* rowptr, const int32_t* col, const void* val, const void* x, int64_t ldx,
          void* out, int64_t ldo, int64_t rows, int64_t dim, const int32_t* long_rows, int64_t n_long, void* stream)
 /* proj(expmap0(spmm(adj, xt))) :150-151, xt = logmap0(x) already in the tangent space (:134);
- * fuse_act != 0 appends HypAct.forward (:170-173) with (c_in, c_out, act) in the same pass */
+ * fuse_act bit 0 appends HypAct.forward (:170-173) with (c_in, c_out, act) in the same pass.  Bits 8-9 of fuse_act pin
+ * the form of the fused row tail, which has two evaluation orders that differ by rounding: 0 = chosen from this
+ * call's rows (four rows per wavefront from 8192 rows on; on the hyperboloid only without long rows), 1 = one row per
+ * wavefront, 2 = four rows per wavefront.  A row shard of a larger graph passes the form the whole graph takes, so
+ * that sharded and unsharded encodes agree bit for bit. */
 HD_DECL2(hd_pb_agg, const int32_t* rowptr, const int32_t* col, const void* val, const void* xt, void* out,
          int64_t rows, int64_t dim, hd_curv c_in, hd_curv c_out, int act, int fuse_act,
          const int32_t* long_rows, int64_t n_long, void* stream)
@@ -322,6 +326,31 @@ int hd_row_pack_bf16x3_f32(const void* x, int mode, hd_curv c, void* out, void* 
                            void* stream);
 int hd_gemm_limbs_f32(const void* A, const void* W, const void* bias, const void* resid, void* C, void* CL,
                       int64_t M, int64_t N, int64_t K, int64_t ldc, int epi, void* stream);
+/* A stack of nn.Linear (+ bias, + exact-erf GELU) layers over MANY rows in ONE persistent launch: the mlp denoiser of
+ * models/direction_diffusion.py:56-69 (fc1 .. fc5 with F.gelu between) over all latent rows of a sampling step.  Same
+ * arithmetic and limb images as hd_gemm_limbs_f32, layer by layer (results are bit-identical to n_layers calls of it);
+ * the tiles of all layers are one stream of work items pulled by the resident workgroups, a 128-row block flows from
+ * layer to layer as soon as its own tiles are complete (csrc/gemm_chain.hip).  A0: limb image of the input (rows, K_0).
+ * Layer i: W = limb image of the weight (N, K), bias (N floats or null), epi 0 none / 1 GELU; out_image = limb image
+ * of the output (required for every layer but the last: hd_limb_image_bytes(rows, N) bytes, written by this call,
+ * distinct buffers per layer), out_f32 = fp32 output with row pitch ldc (optional; the last layer needs one of the
+ * two).  K of layer i must equal N of layer i - 1; at most 8 layers.  workspace: hd_mlp_chain_workspace_bytes(rows,
+ * n_layers) bytes of device memory, 16-byte aligned, ZERO-FILLED ONCE by the caller when it is allocated and from then
+ * on only passed to this function; private to the call while it runs (one workspace per stream).  Never synchronises.
+ * Every device-side wait is bounded (2 s): after a time-out the last layer's fp32 output is filled with NaN and
+ * hd_mlp_chain_failed(workspace, stream) -- which DOES synchronise the stream -- returns 1 once and clears the flag. */
+typedef struct hd_mlp_chain_layer {
+    const void* W;
+    const void* bias;
+    void* out_image;
+    void* out_f32;
+    int64_t N, K, ldc;
+    int32_t epi;
+} hd_mlp_chain_layer;
+int64_t hd_mlp_chain_workspace_bytes(int64_t rows, int n_layers);
+int hd_mlp_chain_limbs_f32(const void* A0, int64_t rows, const hd_mlp_chain_layer* layers, int n_layers, void* workspace,
+                           int64_t workspace_bytes, void* stream);
+int hd_mlp_chain_failed(void* workspace, void* stream);
 /* ---- limb images of two row-scaled fp16 limbs ("f16x2"): half the matrix-core work ----
  * a * 2^ex[row] = a_h + a_l (fp16, 22 significant bits), three limb products (hh, hl, lh) per fp32
  * product on v_mfma_f32_16x16x32_f16, the row exponents removed exactly from the accumulator.

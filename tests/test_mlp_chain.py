@@ -1,0 +1,93 @@
+"""hd_mlp_chain_limbs_f32 (csrc/gemm_chain.hip): the mlp denoiser's five Linear layers (models/direction_diffusion.py:56-69)
+as ONE persistent launch must give, bit for bit, what five hd_gemm_limbs_f32 launches give (same tiles, same K order,
+same write-out arithmetic) -- on the denoiser's own shapes at configs[1]'s row count, on ragged shapes (rows, N and K
+off every tile boundary), and launch after launch on one workspace (the kernel cleans it itself)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _layers(dims, seed, dev, bias=True):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for i in range(len(dims) - 1):
+        k, n = dims[i], dims[i + 1]
+        w = (torch.randn(n, k, generator=g) / k ** 0.5).to(dev)
+        b = torch.randn(n, generator=g).to(dev) if bias else None
+        out.append((w, b, 0 if i == len(dims) - 2 else 1))
+    return out
+
+
+def _per_layer(ops, a, layers):
+    xf = None
+    for i, (w, b, epi) in enumerate(layers):
+        last = i == len(layers) - 1
+        wl, _ = ops.weight_limbs(w, "bf16x3")
+        xf, a = ops.gemm_limbs(a, wl, b, epi=epi, want_f32=last, want_limbs=not last)
+    return xf
+
+
+@pytest.mark.parametrize("rows,dims", [
+    (15777, [513, 800, 900, 800, 700, 512]),        # configs[1]: the bench workload's denoiser
+    (7850, [15, 800, 900, 800, 700, 14]),           # configs[0]: D = 14
+    (4099, [33, 70, 129, 5]),                       # rows, N and K off every boundary; a 1-tile last layer
+    (4096, [64, 64]),                               # single layer is refused by the wrapper -> per-layer path
+    (5000, [100, 96, 32, 31, 200]),                 # tiles of fewer than 4 K slabs: the blocking successor path
+])
+def test_chain_equals_per_layer_launches(rows, dims):
+    from hypdiff_amd import ops
+    dev = "cuda:0"
+    torch.manual_seed(1)
+    x = torch.randn(rows, dims[0], device=dev)
+    layers = _layers(dims, 7, dev)
+    a = ops.limb_pack(x)
+    ref = _per_layer(ops, a, layers)
+    if len(layers) < 2:
+        assert not ops.mlp_chain_ok(a, layers)
+        return
+    assert ops.mlp_chain_ok(a, layers)
+    for rep in range(3):                              # launch after launch on the same workspace
+        got = ops.mlp_chain(a, layers)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref), (rep, float((got - ref).abs().max()))
+    assert not ops.mlp_chain_failed()
+
+
+def test_chain_matches_fp64_and_linear_chain_routes_to_it():
+    """ops.linear_chain takes the one-launch path for a big bf16x3 stack; result within fp32 rounding of fp64"""
+    from hypdiff_amd import ops
+    dev = "cuda:0"
+    rows, dims = 6000, [513, 800, 900, 800, 700, 512]
+    torch.manual_seed(2)
+    x = torch.randn(rows, dims[0], device=dev)
+    layers = _layers(dims, 11, dev)
+    mode = ops.GEMM_MODE
+    ops.GEMM_MODE = "bf16x3"
+    try:
+        got = ops.linear_chain(x, layers)
+    finally:
+        ops.GEMM_MODE = mode
+    h = x.double()
+    for w, b, epi in layers:
+        h = h @ w.double().T + b.double()
+        if epi == 1:
+            h = torch.nn.functional.gelu(h)
+    err = float((got.double() - h).abs().max() / h.abs().max())
+    assert err < 3e-6, err                              # five chained fp32 GEMMs
+
+
+def test_chain_no_bias_and_many_launches_stay_clean():
+    from hypdiff_amd import ops
+    dev = "cuda:0"
+    rows, dims = 9000, [128, 256, 192, 64]
+    torch.manual_seed(3)
+    x = torch.randn(rows, dims[0], device=dev)
+    layers = _layers(dims, 5, dev, bias=False)
+    a = ops.limb_pack(x)
+    ref = _per_layer(ops, a, layers)
+    outs = [ops.mlp_chain(a, layers) for _ in range(20)]      # back to back, no host sync in between
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, ref) for o in outs)
+    assert not ops.mlp_chain_failed()

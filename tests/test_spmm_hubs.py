@@ -145,9 +145,10 @@ def test_sharded_encode_with_hubs(hub_graph, mname, c):
     """dist.sharded_hgcn_encode on the hub graph: world 1 through the function, world 2 / 3 simulated
     in-process (all-gather = concatenation of the padded blocks; the collective itself runs in
     tests/test_dist_gloo.py and tests/test_dist_nccl.py).  Shard rows keep the 1-GPU kernel's per-row
-    summation order -> bit-identical to the unsharded encode where both take the same form of the fused tail;
+    summation order and the whole graph's form of the fused tail -> bit-identical to the unsharded encode (also
+    where a shard alone would pick the other form: the Hyperboloid graph has long rows, a world-3 shard may have none);
     the unsharded encode against the oracle."""
-    from hypdiff_amd import dist as hdist
+    from hypdiff_amd import dist as hdist, ops
     from hypdiff_amd.models.encoders import HGCN, _lift
     g = hub_graph
     feat, dim = 64, 256
@@ -162,6 +163,7 @@ def test_sharded_encode_with_hubs(hub_graph, mname, c):
     adj = torch.sparse_coo_tensor(G(g["idx"]), G(g["val"]), g["shape"], check_invariants=False)
     with torch.no_grad():
         full = enc.encode(G(x), adj)
+        full_csr = ops.csr_of(adj)
         Ws = [l.linear.weight.detach().cpu() for l in enc.layers]
         ref = olayers.hgcn_encode(mname, torch.from_numpy(x), (torch.from_numpy(g["idx"]), torch.from_numpy(g["val"]),
                                                                 g["shape"]), Ws, [c, c, c], prepend_time=False)
@@ -177,14 +179,10 @@ def test_sharded_encode_with_hubs(hub_graph, mname, c):
                 gathered = torch.cat([torch.cat([xt, xt.new_zeros(s.rows_per_rank - xt.shape[0], xt.shape[1])])
                                       for s, xt in zip(shards, xts)])
                 hs = [hdist.shard_aggregate(layer, hdist.shard_csr(s, "cuda"), gathered, s.hi - s.lo) for s in shards]
-            # Shards keep the 1-GPU kernel's per-row summation order.  The fused tail has two forms (four rows per
-            # wavefront with the analytic factor from 8192 rows on, one row per wavefront below: csrc/hd_spmm.cuh), which
-            # differ by rounding: bit-identical when shard and full graph take the same form, a few ulp otherwise.
-            same_form = all((s.rows_per_rank >= 8192) == (N >= 8192) for s in shards)
-            if same_form:
-                assert torch.equal(torch.cat(hs), full), world
-            else:
-                assert_close(H(torch.cat(hs)), H(full), rtol=2e-6, atol_scale=2e-7, what=f"sharded x{world} vs full")
+            # Shards keep the 1-GPU kernel's per-row summation order AND run the form of the fused tail (one / four rows
+            # per wavefront, csrc/hd_spmm.cuh) that the whole graph takes (dist.shard_csr -> csr.whole): bit-identical.
+            assert all(hdist.shard_csr(s, "cuda").whole == (N, full_csr.n_long) for s in shards)
+            assert torch.equal(torch.cat(hs), full), world
 
 
 def test_config5_full_size_properties():
