@@ -204,7 +204,9 @@ def gemm_limbs_train(a, w, bias, aux, epi, want_z=False, want_f32=True, want_lim
 def _limb_stack_ok(x, kinds, ws_):
     """The stack can run on the persistent limb GEMM: fp32-faithful limb arithmetic allowed (not GEMM_MODE "exact"),
     no residual layers (the mlp denoiser: GELU ... GELU, LIN), rows of 16-byte multiples, no gradient for x."""
-    return (ops.GEMM_MODE != "exact" and not x.requires_grad and all(k in (GELU, LIN) for k in kinds) and kinds[-1] == LIN
+    # (every layer but the last is GELU: the input-gradient GEMM of _backward_limbs multiplies by gelu'(z_below) in its
+    # write-out; a LIN layer in the middle has no z_below and takes the on-the-fly kernels instead)
+    return (ops.GEMM_MODE != "exact" and not x.requires_grad and all(k == GELU for k in kinds[:-1]) and kinds[-1] == LIN
             and x.shape[0] > 0 and all(w.shape[0] % 4 == 0 for w in ws_))
 
 

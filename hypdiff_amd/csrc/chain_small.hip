@@ -33,6 +33,7 @@
 #include "hd_gelu.cuh"
 #include "hd_limbs.cuh"
 #include "../../include/hypdiff.h"
+#include <stdlib.h>
 
 using namespace hd;
 
@@ -56,7 +57,7 @@ struct Chain {
 };
 
 // workspace: header (int 0: launches completed mod kEpochs, int 1: workgroups that have left the running launch,
-// int 32: fail flag), then the two word buffers [group][row tile][k-step][element 0..7 of the lane][lane]: a
+// int 32: fail flag of the running launch, int 33: sticky report for hd_chain_failed), then the two word buffers [group][row tile][k-step][element 0..7 of the lane][lane]: a
 // wavefront's load / store instruction covers 512 contiguous bytes
 typedef unsigned long long u64;
 constexpr size_t kGroupWords = (size_t)kMaxRT * kMaxKS * 8 * 64;
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void linear_chain_small(const float* __restric
                                                           Chain ch, const float* __restrict__ emb,
                                                           const int64_t* __restrict__ emb_idx, int emb_rows,
                                                           float* __restrict__ out, int64_t ldo, int* hdr, u64* buf0,
-                                                          u64* buf1, int RT) {
+                                                          u64* buf1, int RT, int withhold) {
     __shared__ float4 red[4][2 * kMaxRT][64];
     __shared__ int bad_s, last_s;
     const int grp = blockIdx.x & (kGroups - 1), g = blockIdx.x >> 4;
@@ -105,7 +106,9 @@ __global__ __launch_bounds__(256) void linear_chain_small(const float* __restric
         {
             const int K0 = ch.l[0].K, KS0 = (K0 + 31) >> 5;
             const unsigned tag = (unsigned)(epoch << 5);
-            for (int p = g * 4 + wave; p < nrt * KS0; p += kG * 4) {
+            // (withhold: tests only -- group 0's first member never publishes its share of the input, so every consumer
+            // of the group runs into the bounded wait: tests/test_ddpm.py::test_chain_small_timeout_and_recovery)
+            for (int p = g * 4 + wave; p < nrt * KS0 && !(withhold && grp == 0 && g == 0); p += kG * 4) {
                 const int it = p / KS0, ks = p - it * KS0;
                 const int row = r0 + it * 16 + r16;
                 u64* o = gb0 + (size_t)(it * kMaxKS + ks) * 8 * 64 + lane;
@@ -302,7 +305,12 @@ __global__ __launch_bounds__(256) void linear_chain_small(const float* __restric
             for (size_t i = tid; i < kBufWords; i += blockDim.x) { st_w(buf0 + i, 0); st_w(buf1 + i, 0); }
         }
         __syncthreads();
-        if (tid == 0) { hdr[0] = done; hdr[1] = 0; }
+        // the fail word is per launch: the last workgroup out moves it to the sticky report word (read and cleared by
+        // hd_chain_failed) and clears it, so a launch that timed out poisons its own outputs only
+        if (tid == 0) {
+            if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { hdr[33] = 1; hdr[32] = 0; }
+            hdr[0] = done; hdr[1] = 0;
+        }
     }
 }
 
@@ -377,7 +385,9 @@ extern "C" int hd_linear_chain_small_f32(const void* x, int64_t ldx, int64_t row
     const float* ep = (const float*)emb;
     float* op = (float*)out;
     int rows_i = (int)rows, emb_rows_i = (int)(emb_rows < 0x7fffffff ? emb_rows : 0x7fffffff);
-    void* args[] = {&xp, &ldx, &rows_i, &ch, &ep, &emb_idx, &emb_rows_i, &op, &ldo, &hdr, &buf0, &buf1, &RT};
+    const char* wh = getenv("HD_CHAIN_TEST_WITHHOLD");                  // tests: force the time-out path (see the kernel)
+    int withhold = wh && wh[0] == '1';
+    void* args[] = {&xp, &ldx, &rows_i, &ch, &ep, &emb_idx, &emb_rows_i, &op, &ldo, &hdr, &buf0, &buf1, &RT, &withhold};
     e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(linear_chain_small), dim3(kGroups * kG), dim3(256), args,
                                    0, (hipStream_t)st);
     if (e != hipSuccess) {
@@ -387,15 +397,14 @@ extern "C" int hd_linear_chain_small_f32(const void* x, int64_t ldx, int64_t row
     return HD_OK;
 }
 
-// 1 after a launch in which a wait timed out (its outputs are NaN); reads the workspace (synchronises the stream)
+// 1 if a wait timed out in any launch on this workspace since the last query (the outputs of THAT launch are NaN; later
+// launches are clean: the kernel clears its fail word when it leaves and keeps a report word for this query); clears the
+// report.  Reads device memory: synchronises the stream once.  The launch itself never synchronises.
 extern "C" int hd_chain_failed(void* workspace, void* st) {
     int f = 0;
     if (!workspace) return 0;
-    if (hipMemcpyAsync(&f, (const char*)workspace + 128, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)st) != hipSuccess) return -1;
+    if (hipMemcpyAsync(&f, (const char*)workspace + 132, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)st) != hipSuccess) return -1;
     if (hipStreamSynchronize((hipStream_t)st) != hipSuccess) return -1;
-    if (f != 0) {                                              // the flag is sticky: reading it clears it
-        if (hipMemsetAsync((char*)workspace + 128, 0, 4, (hipStream_t)st) != hipSuccess) return -1;
-        if (hipStreamSynchronize((hipStream_t)st) != hipSuccess) return -1;
-    }
-    return f;
+    if (f != 0 && hipMemsetAsync((char*)workspace + 132, 0, 4, (hipStream_t)st) != hipSuccess) return -1;
+    return f != 0;
 }

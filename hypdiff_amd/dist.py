@@ -106,7 +106,7 @@ class GradBucket:
         if hi > 0:
             self.chunks.append((0, hi))
         self._pending = {c: sum(1 for p in self.params if c[0] <= self.offsets[id(p)][0] < c[1]) for c in self.chunks}
-        self._left, self._works, self._hooks = {}, [], []
+        self._left, self._works, self._hooks, self._delivered = {}, [], [], set()
 
     def zero_(self):
         self.flat.zero_()
@@ -129,6 +129,7 @@ class GradBucket:
         (post-accumulate hooks) and launch the chunk's all-reduce when it is complete."""
         self._left = dict(self._pending)
         self._works = []
+        self._delivered = set()
         self._group = group
         if not self._hooks:
             for p in self.params:
@@ -139,11 +140,20 @@ class GradBucket:
         buckets only; hypdiff_amd.autograd.GRAD_SINK), or None."""
         if not self._left or id(p) not in self.offsets:
             return None
+        if id(p) in self._delivered:          # before anything is overwritten
+            raise RuntimeError("GradBucket: a second gradient for a parameter already delivered in this step (module "
+                               "applied twice / shared weights): use DataParallelTrainer(..., overlap=False) for such a loss")
         lo, hi = self.offsets[id(p)]
         return self.flat[lo:hi].view_as(p)
 
     def delivered(self, p):
-        """p's gradient has been written into view_for(p) (enqueued on the current stream)"""
+        """p's gradient has been WRITTEN (not accumulated) into view_for(p), enqueued on the current stream.  A
+        parameter may be delivered once per armed step: a second delivery (the same module applied twice in one loss,
+        shared weights) would overwrite the first contribution after its chunk may already be on the wire."""
+        if id(p) in self._delivered:
+            raise RuntimeError("GradBucket: a parameter's gradient was delivered twice in one step (module applied twice / "
+                               "shared weights): run DataParallelTrainer(..., overlap=False) for such a loss")
+        self._delivered.add(id(p))
         self._on_grad(p)
 
     def _on_grad(self, p):

@@ -28,3 +28,21 @@ class Manifold(object):
 
 for _name, _sig in API.items():
     setattr(Manifold, _name, _abstract(_name, _sig))
+
+
+import torch  # noqa: E402
+
+
+class ManifoldParameter(torch.nn.Parameter):
+    """nn.Parameter that remembers the manifold and curvature it lives on (manifolds/base.py:76-88: what
+    optimizers/radam.py keys its Riemannian update on).  Construction and repr follow the reference; a parameter of
+    this type is an ordinary leaf tensor for everything else."""
+
+    def __new__(cls, data, requires_grad, manifold, c):
+        return super().__new__(cls, data, requires_grad)
+
+    def __init__(self, data, requires_grad, manifold, c):
+        self.manifold, self.c = manifold, c
+
+    def __repr__(self):
+        return f"{self.manifold.name} Parameter containing:\n{torch.Tensor.__repr__(self)}"

@@ -579,6 +579,16 @@ def mlp_chain_failed():
     return bad
 
 
+def chain_small_failed():
+    """True if a device-side wait of any hd_linear_chain_small_f32 launch timed out since the last call (the outputs
+    of that launch are NaN; later launches are clean).  Synchronises the streams that own a workspace: tests and
+    post-mortems only -- the hot path never reads the flag, a failed launch is visible as NaN outputs."""
+    bad = False
+    for (_, stream), ws in _chain_ws.items():
+        bad |= _lib.load().hd_chain_failed(_p(ws), ctypes.c_void_p(stream)) == 1
+    return bad
+
+
 CHAIN_SMALL_MAX_ROWS, CHAIN_SMALL_MAX_WIDTH = 512, 512
 _NO_CHAIN_SMALL = bool(os.environ.get("HD_NO_CHAIN_SMALL"))     # debugging knob: one GEMM launch per layer
 _chain_ws = {}

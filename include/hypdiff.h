@@ -299,9 +299,11 @@ int hd_limb_unpack_f32(const void* in, int64_t rows, int64_t cols, void* out, in
  * inner widths are multiples of 32.  Arithmetic as hd_gemm_limbs_f32 (3 bf16 limbs, fp32-faithful).  workspace:
  * hd_chain_workspace_bytes() bytes of device memory, 16-byte aligned, ZERO-FILLED ONCE by the caller when it is
  * allocated and from then on only passed to this function, private to the call while it runs (at most 31 layers).  The launch
- * is cooperative (hipLaunchCooperativeKernel: 256 workgroups resident at once); hd_chain_failed(workspace, stream)
- * returns 1 if a wait of any launch since the last query timed out (outputs are NaN then) and clears the flag -- it
- * synchronises the stream. */
+ * is cooperative (hipLaunchCooperativeKernel: 256 workgroups resident at once) and never synchronises.  Every device-side
+ * wait is bounded (2 s); a launch in which one timed out writes NaN outputs -- that launch only: the kernel clears its
+ * fail word when it leaves, the next launch on the workspace is clean.  hd_chain_failed(workspace, stream) returns 1 if
+ * that happened in any launch since the last query and clears the report; it reads device memory, i.e. it synchronises
+ * the stream (once). */
 typedef struct {
     const void* wimg;
     const void* bias;

@@ -112,12 +112,15 @@ def test_config2_bench_workload_vs_oracle(gemm_mode):
 
 
 @ALL_MODES
-def test_config4_citation_encode_vs_oracle(gemm_mode):
-    """N = 2708, identity features -> the K = 2708 HypLinear GEMM (rows past the one-pass producers' limit),
-    D = 512, c = 0.6, PoincareBall; plus the link-prediction decoder on the embeddings."""
+@pytest.mark.parametrize("n,m", [(2708, 2), (3327, 2)])
+def test_config4_citation_encode_vs_oracle(gemm_mode, n, m):
+    """Cora-shaped (N = 2708) and Citeseer-shaped (N = 3327) halves of configs[3]: identity features of width N
+    (utils/data_utils.py:171 forces them) -> the K = N HypLinear GEMM (rows past the one-pass producers' limit; K = 3327
+    is odd: 16-byte row padding, the streaming long-row kernel on unaligned rows and the split-K GEMM with a ragged
+    last slab take branches N = 2708 does not), D = 512, c = 0.6, PoincareBall."""
     from hypdiff_amd import workloads
-    n, dim, c = 2708, 512, 0.6
-    adj = workloads.citation_graph(n)
+    dim, c = 512, 0.6
+    adj = workloads.citation_graph(n, m)
     idx, val, shape = adjacency.process_adj(adj)
     x = torch.eye(n)
     enc = _encoder("PoincareBall", c, n, dim, 11)
@@ -126,8 +129,9 @@ def test_config4_citation_encode_vs_oracle(gemm_mode):
         h = enc.encode(x.cuda(), adj_t)
     want = _oracle_encode("PoincareBall", c, x, idx, val, shape, enc, torch.float32)
     ex = _oracle_encode("PoincareBall", c, x, idx, val, shape, enc, torch.float64)
-    _report("config 4: 2708 x 2708 -> 512", gemm_mode, [("HGCN.encode (PoincareBall)", H(h), want)])
-    assert_close(H(h), want, exact=ex, what="config 4 encode")
+    _report(f"config 4: {n} x {n} -> 512", gemm_mode, [("HGCN.encode (PoincareBall)", H(h), want)])
+    assert h.shape == (n, dim)
+    assert_close(H(h), want, exact=ex, what=f"config 4 encode N={n}")
 
 
 @ALL_MODES

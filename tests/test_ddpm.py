@@ -176,6 +176,42 @@ def test_linear_chain_small_shapes():
 
 
 @pytest.mark.gpu
+def test_chain_small_timeout_and_recovery():
+    """The bounded wait of hd_linear_chain_small_f32, exercised: with HD_CHAIN_TEST_WITHHOLD=1 one producer never
+    publishes its share of the input, its consumers run into the 2 s bound, the launch ends (no hang), its outputs are
+    NaN, hd_chain_failed reports 1 exactly once -- and the NEXT launch on the same workspace is clean (the fail word is
+    per launch), bit-identical to a launch before the failure."""
+    import os
+    import time
+    from hypdiff_amd import ops
+    rs = np.random.RandomState(11)
+    dims, epis = [64, 512, 512, 64], [1, 2, 0]
+    ws = [torch.from_numpy((rs.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32)).cuda() for i in range(3)]
+    bs = [torch.from_numpy(rs.standard_normal(dims[i + 1]).astype(np.float32)).cuda() for i in range(3)]
+    x = torch.from_numpy(rs.standard_normal((200, 64)).astype(np.float32)).cuda()
+    layers = list(zip(ws, bs, epis))
+    good = ops.linear_chain_small(x, layers)
+    torch.cuda.synchronize()
+    assert torch.isfinite(good).all() and not ops.chain_small_failed()
+    os.environ["HD_CHAIN_TEST_WITHHOLD"] = "1"
+    try:
+        t0 = time.perf_counter()
+        bad = ops.linear_chain_small(x, layers)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        os.environ.pop("HD_CHAIN_TEST_WITHHOLD", None)
+    assert 1.5 < dt < 30.0, dt                                  # ended by the bound, not by luck and not by a hang
+    assert torch.isnan(bad[:16]).any()                           # the rows fed by the withheld tile
+    again = ops.linear_chain_small(x, layers)                    # no query in between: recovery does not depend on one
+    torch.cuda.synchronize()
+    assert torch.equal(again, good)
+    assert ops.chain_small_failed()                              # reported once ...
+    assert not ops.chain_small_failed()                          # ... and cleared
+    assert torch.equal(ops.linear_chain_small(x, layers), good)
+
+
+@pytest.mark.gpu
 def test_graphed_train_step_equals_eager():
     """DataParallelTrainer.capture: the whole ddpm.Model training step (loss, backward, one-launch Adam with its step
     count on the device) as one HIP graph.  3 warm-up steps + 2 replays leave exactly the parameters of 5 eager steps;

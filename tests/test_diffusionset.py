@@ -84,7 +84,10 @@ def test_hip_diffusionset_golden(golden):
         x = C("c/x")
         ret = d.p_sample_loop(x, 1, labels, u0, graphset=True, img=C("c/img"))
         assert_close(x.cpu(), g["p_sample_loop/x_after"], what="x mutated")
-        assert_close(ret.cpu(), g["p_sample_loop/ret"], rtol=1e-3, atol_scale=1e-4, what="loop")
+        # 200 chained fp32 denoiser evaluations: 1e-5 + 3 D with D = 3e-6, the drift fp32 arithmetic itself causes over the
+        # loop (measured step by step for the node-level class in tests/test_gpu_parity.py::test_loop_drift_stays_within_fp32s_own;
+        # the graph-set loop runs the same denoiser and schedule)
+        assert_close(ret.cpu(), g["p_sample_loop/ret"], rtol=1e-5, atol_scale=1e-5, what="loop end point (1e-5 + 3 D)")
 
 
 @pytest.mark.gpu

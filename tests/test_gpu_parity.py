@@ -371,7 +371,7 @@ def test_layers_golden(golden, kind, n, mname, c):
                 assert_close(H(lyr.agg(G(g[k + f"L{i}/linear"]), adj)), g[k + f"L{i}/agg"], what=k + f"L{i}/agg")
                 assert_close(H(lyr.hyp_act(G(g[k + f"L{i}/agg"]))), g[k + f"L{i}/act"], what=k + f"L{i}/act")
                 fused, _ = lyr((hin, adj))
-                assert_close(H(fused), g[k + f"L{i}/act"], rtol=2e-5, atol_scale=2e-6, what=k + f"L{i}/fused")
+                assert_close(H(fused), g[k + f"L{i}/act"], what=k + f"L{i}/fused")      # plain bar: uses <= 0.18 of it (profiles/r03_parity_margin.json)
 
 
 @BOTH_GEMMS
@@ -395,7 +395,7 @@ def test_hgcn_encode_golden(golden, kind, n, mname, c, gemm_mode):
         x = torch.cat([torch.zeros_like(x[:, :1]), x], 1)       # models/base_models.py:79-81
     with torch.no_grad():
         out = enc.encode(x, _adj(g, k0, n))
-    assert_close(H(out), g[k + "encode"], rtol=3e-5, atol_scale=3e-6, what=k + "encode")
+    assert_close(H(out), g[k + "encode"], what=k + "encode")                 # plain bar: uses <= 0.26 of it
     # LPModel: encode through the wrapper (zero time column prepended for the hyperboloid) + edge decoder
     from hypdiff_amd.models.base_models import LPModel
     largs = types.SimpleNamespace(manifold=mname, c=c, cuda=0, device="cuda:0", feat_dim=n, n_nodes=n, model="HGCN",
@@ -406,7 +406,7 @@ def test_hgcn_encode_golden(golden, kind, n, mname, c, gemm_mode):
         lyr.linear.load_state_dict({"weight": torch.from_numpy(g[k + f"W{i}"]), "bias": torch.from_numpy(g[k + f"b{i}"])})
     with torch.no_grad():
         emb, _, _, _ = lp.encode(G(g[k0 + "features"]), _adj(g, k0, n))
-        assert_close(H(emb), g[k + "encode"], rtol=3e-5, atol_scale=3e-6, what=k + "lp encode")
+        assert_close(H(emb), g[k + "encode"], what=k + "lp encode")
         probs = lp.decode(G(g[k + "encode"]), G(g[k0 + "train_edges"]))
     ex = olayers.lp_decode(mname, torch.from_numpy(g[k + "encode"]).double(), torch.from_numpy(g[k0 + "train_edges"]), c, 2.0, 1.0)
     assert_close(H(probs), g[k + "decode_train"], what=k + "decode", exact=ex.numpy())
@@ -693,6 +693,11 @@ def test_mlp_and_p_sample_golden(golden, gemm_mode):
                                  scale=max(raw, float(np.abs(g[key + "pred"]).max())))
 
 
+def ops_labels(labels):
+    from hypdiff_amd import ops
+    return ops.labels_dev(labels, "cuda")
+
+
 def test_forward_loss_and_loop_golden(golden):
     g = golden("diffusion")
     d = _diff()
@@ -708,8 +713,61 @@ def test_forward_loss_and_loop_golden(golden):
         x = G(g["c/x"], torch.float32)
         ret = d.p_sample_loop(x, 1, labels, u0, graphset=True, img=G(g["c/img"]))
         assert_close(H(x), g["p_sample_loop/f32/x_after"], what="loop x mutated")
-        # 200 chained fp32 denoiser evaluations compound rounding: looser end-point bar
-        assert_close(H(ret), g["p_sample_loop/f32/ret"], rtol=1e-3, atol_scale=1e-4, what="loop")
+        # the end point against the reference's: 1e-5 + 3 D, D = the drift fp32 arithmetic itself causes over the 200
+        # steps (oracle loop with the denoiser in fp32 vs in fp64, tests/loop_drift.py; D = 3e-6) -- see
+        # test_loop_drift_stays_within_fp32s_own for the step-by-step picture
+        from loop_drift import oracle_loop_states
+        params = [(torch.from_numpy(w), torch.from_numpy(b)) for w, b in gi.mlp_params(16)]
+        args = (torch.from_numpy(g["c/x"]).float(), labels, torch.from_numpy(g["c/u0"]), torch.from_numpy(g["c/img"]),
+                odiff.schedule(200), params)
+        _, e32 = oracle_loop_states(*args, exact=False)
+        _, e64 = oracle_loop_states(*args, exact=True)
+        D = float((e32 - e64).abs().max() / e64.abs().max())
+        assert D < 1e-5, D
+        assert_close(H(ret), g["p_sample_loop/f32/ret"], rtol=1e-5, atol_scale=1e-6 + 3 * D, what="loop end point (1e-5 + 3 D)")
+
+
+@BOTH_GEMMS
+def test_loop_drift_stays_within_fp32s_own(golden, gemm_mode):
+    """p_sample_loop step by step (T = 200): after every step the distance of the HIP state from the exact trajectory
+    (oracle loop with the denoiser in fp64) next to the distance of the oracle's fp32 loop from it.  fp32 rounding is
+    carried from step to step but does not blow up (it peaks at ~3e-6 around step 10-50 and shrinks as the schedule
+    contracts).  The HIP path is another fp32 evaluation with its own summation order: measured on MI355X it peaks at
+    7.3e-6 with the bit-exact fp32-MFMA GEMMs (`exact`: a sequential fmaf chain over K <= 900, where the CPU's blocked
+    sgemm sums pairwise-like), 8.9e-6 under f16x2 and 1.17e-5 under bf16x3 -- 2.3x / 2.9x / 3.8x the oracle's own worst
+    -- and ends at 1.0e-6 / 3.3e-6 / 3.9e-6 (oracle 5e-7).  Asserted: at EVERY step within 5x the oracle's worst drift
+    and within 2e-5 of the exact trajectory -- a measured model of the growth instead of a loose end-point tolerance."""
+    from loop_drift import drift, oracle_loop_states
+    g = golden("diffusion")
+    d = _diff()
+    u0 = G(g["c/u0"])
+    labels = g["c/labels"]
+    params = [(torch.from_numpy(w), torch.from_numpy(b)) for w, b in gi.mlp_params(16)]
+    args = (torch.from_numpy(g["c/x"]).float(), labels, torch.from_numpy(g["c/u0"]), torch.from_numpy(g["c/img"]),
+            odiff.schedule(200), params)
+    s32, _ = oracle_loop_states(*args, exact=False)
+    s64, _ = oracle_loop_states(*args, exact=True)
+    with torch.no_grad():                               # the product's loop, :293-332, one step at a time
+        x = G(g["c/x"], torch.float32)
+        direction = d.directions(u0)
+        lab = ops_labels(labels)
+        img = d.tran_direction(direction, G(g["c/img"]).clone(), lab)
+        h = d._logmap_centres(x, lab, u0)
+        img = img + d._apply_moments(h, d.moments(h), 0)
+        states = [img.cpu()]
+        for t in reversed(range(200)):
+            img, _ = d.p_sample(img, None, 1, direction, lab, u0, t, None, True)
+            states.append(img.cpu())
+    own = drift(s32, s64)
+    hip = drift(states, s64)
+    worst = own.max()
+    print(f"\n[loop drift, GEMM_MODE={gemm_mode}] oracle fp32 vs exact: max {worst:.2e} at step {own.argmax()}, end {own[-1]:.2e}; "
+          f"HIP vs exact: max {hip.max():.2e} at step {hip.argmax()}, end {hip[-1]:.2e}; largest HIP / oracle-worst {hip.max() / worst:.2f}")
+    from conftest import record_margin
+    record_margin("loop drift", max_norm_rel=float(hip.max()), plain_bar_used=float(hip.max() / 1e-5), bound_used=float(hip.max() / min(5 * worst, 2e-5)),
+                  oracle_fp32_drift_max=float(worst), hip_drift_end=float(hip[-1]), oracle_fp32_drift_end=float(own[-1]), steps=200)
+    assert worst < 1e-5
+    assert (hip <= min(5 * worst, 2e-5)).all(), (hip.max(), worst)
 
 
 def test_full_size_properties():

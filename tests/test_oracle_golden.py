@@ -109,7 +109,7 @@ def test_layers(golden, kind, n, mname, c):
             h3 = olayers.hyp_act(mname, T(g[k + f"L{i}/agg"]), c, c)
             assert_close(h3, g[k + f"L{i}/act"], what=k + f"L{i}/act")
         enc = olayers.hgcn_encode(mname, feats, adj, Ws, [c, c, c], bs)
-        assert_close(enc, g[k + "encode"], rtol=2e-5, atol_scale=2e-6, what=k + "encode")
+        assert_close(enc, g[k + "encode"], what=k + "encode")      # plain bar (uses <= 0.18 of it)
         dec = olayers.lp_decode(mname, T(g[k + "encode"]), T(g[k0 + "train_edges"]), c, 2.0, 1.0)
         assert_close(dec, g[k + "decode_train"], what=k + "decode")
 
@@ -198,6 +198,15 @@ def test_forward_loss_and_loop(golden):
                                                 tb, params)
         assert_close(loss, g[f"forward/{tag}/loss"], what="loss " + tag)
     ret = odiff.p_sample_loop(T(g["c/x"], torch.float32), labels, u0, T(g["c/img"]), tb, params)
-    # 200 chained fp32 denoiser evaluations: rounding differences compound, so the
-    # end point is checked at a looser bar than a single step
-    assert_close(ret, g["p_sample_loop/f32/ret"], rtol=1e-3, atol_scale=1e-4, what="loop")
+    # 200 chained fp32 denoiser evaluations: two correct fp32 evaluations (the reference's sgemm blocking, ours) differ
+    # by rounding that is carried from step to step.  How far is measured, not guessed (tests/loop_drift.py): the same
+    # loop with the denoiser in fp64 is the exact yardstick, the fp32 loop sits D = 3e-6 (max-norm, relative) from it
+    # at the end point, and the reference's own end point may sit as far on the other side.
+    from loop_drift import oracle_loop_states
+    x32 = T(g["c/x"], torch.float32)
+    _, e32 = oracle_loop_states(x32, labels, u0, T(g["c/img"]), tb, params, exact=False)
+    _, e64 = oracle_loop_states(x32, labels, u0, T(g["c/img"]), tb, params, exact=True)
+    assert torch.equal(e32, ret)
+    D = float((e32 - e64).abs().max() / e64.abs().max())
+    assert D < 1e-5, D
+    assert_close(ret, g["p_sample_loop/f32/ret"], rtol=1e-5, atol_scale=1e-6 + 3 * D, what="loop end point (1e-5 + 3 D)")
