@@ -84,6 +84,8 @@ SIGNATURES = {
     "hd_hb_hyp_act*": _act,
     "hd_rownorm*": [P, P, I64, I64, P],
     "hd_pb_map_bwd*": [c_int, P, P, P, I64, I64, HdCurv, P], "hd_hb_map_bwd*": [c_int, P, P, P, I64, I64, HdCurv, P],
+    "hd_pb_map2_bwd*": [c_int, P, P, P, P, P, I64, I64, HdCurv, P],
+    "hd_pb_sqdist_bwd*": [P, P, P, P, P, I64, I64, HdCurv, P], "hd_hb_sqdist_bwd*": [P, P, P, P, P, I64, I64, HdCurv, P],
     "hd_pb_linear_tail_bwd*": [P, P, P, P, P, I64, I64, HdCurv, c_int, P],
     "hd_hb_linear_tail_bwd*": [P, P, P, I64, I64, HdCurv, c_int, P],
     "hd_pb_agg_tail*": [P, P, I64, I64, HdCurv, HdCurv, c_int, c_int, P],

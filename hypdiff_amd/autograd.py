@@ -467,6 +467,58 @@ class RowMap(torch.autograd.Function):
         return out.view(shape), None, None, None
 
 
+class RowMap2(torch.autograd.Function):
+    """mobius_add / expmap / logmap of the Poincare ball on two row operands of equal shape (kernel argument order:
+    ops.map2) with the VJP kernel hd_pb_map2_bwd (both gradients in one pass; _lambda_x carries no gradient, as in
+    manifolds/poincare.py:34)."""
+
+    CODES = {"hd_pb_mobius_add": 0, "hd_pb_expmap": 1, "hd_pb_logmap": 2}
+
+    @staticmethod
+    def forward(ctx, a, b, name, cv):
+        a2, shape = ops._rows(a)
+        b2, _ = ops._rows(b)
+        out = torch.empty_like(a2)
+        _lib.call(name + ops._sfx(a2), ops._p(a2), ops._p(b2), ops._p(out), a2.shape[0], a2.shape[1], cv, ops._stream())
+        ctx.save_for_backward(a2, b2)
+        ctx.meta = (RowMap2.CODES[name], cv, shape)
+        return out.view(shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        a2, b2 = ctx.saved_tensors
+        which, cv, shape = ctx.meta
+        g2 = g.reshape(a2.shape).contiguous()
+        da, db = torch.empty_like(a2), torch.empty_like(b2)
+        _lib.call("hd_pb_map2_bwd" + ops._sfx(a2), which, ops._p(a2), ops._p(b2), ops._p(g2), ops._p(da), ops._p(db),
+                  a2.shape[0], a2.shape[1], cv, ops._stream())
+        return da.view(shape), db.view(shape), None, None
+
+
+class SqdistFn(torch.autograd.Function):
+    """Manifold.sqdist of two row operands (one scalar per row) with hd_{pb,hb}_sqdist_bwd"""
+
+    @staticmethod
+    def forward(ctx, a, b, name, cv):
+        a2, shape = ops._rows(a)
+        b2, _ = ops._rows(b)
+        out = torch.empty(a2.shape[0], dtype=a2.dtype, device=a2.device)
+        _lib.call(name + ops._sfx(a2), ops._p(a2), ops._p(b2), ops._p(out), a2.shape[0], a2.shape[1], cv, ops._stream())
+        ctx.save_for_backward(a2, b2)
+        ctx.meta = (name, cv, shape)
+        return out.view(shape[:-1])
+
+    @staticmethod
+    def backward(ctx, g):
+        a2, b2 = ctx.saved_tensors
+        name, cv, shape = ctx.meta
+        g1 = g.reshape(-1).contiguous()
+        da, db = torch.empty_like(a2), torch.empty_like(b2)
+        _lib.call(name + "_bwd" + ops._sfx(a2), ops._p(a2), ops._p(b2), ops._p(g1), ops._p(da), ops._p(db), a2.shape[0],
+                  a2.shape[1], cv, ops._stream())
+        return da.view(shape), db.view(shape), None, None
+
+
 class HbProjTan0(torch.autograd.Function):
     """hyperboloid.py:64-68: zero the time column; the VJP is the same map on the gradient"""
 

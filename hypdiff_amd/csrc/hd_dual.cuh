@@ -37,6 +37,20 @@ HD_DUAL_T operator+(const Dual<T, NV>& a, const Dual<T, NV>& b) {
     for (int i = 0; i < NV; ++i) r.d[i] = a.d[i] + b.d[i];
     return r;
 }
+HD_DUAL_T operator-(const Dual<T, NV>& a, const Dual<T, NV>& b) {
+    Dual<T, NV> r;
+    r.v = a.v - b.v;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) r.d[i] = a.d[i] - b.d[i];
+    return r;
+}
+HD_DUAL_T operator-(const Dual<T, NV>& a) {
+    Dual<T, NV> r;
+    r.v = -a.v;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) r.d[i] = -a.d[i];
+    return r;
+}
 HD_DUAL_T operator*(const Dual<T, NV>& a, const Dual<T, NV>& b) {
     Dual<T, NV> r;
     r.v = a.v * b.v;

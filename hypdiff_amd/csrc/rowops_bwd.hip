@@ -349,6 +349,133 @@ int launch_edge_decode_bwd(const char* name, const void* h, const int64_t* pairs
     });
 }
 
+
+// ---- two-point maps of the Poincare ball called on their own (poincare.py:25-31, 55-71, 85-91) ------------------
+// Every one of them is  out = alpha * a + beta * b  with alpha, beta functions of the three row sums
+// (a.a, b.b, a.b): the chain is evaluated on Dual<T, 3> seeded on those sums, and with q_i = d alpha/d s_i <g, a> +
+// d beta/d s_i <g, b>
+//     d a = alpha g + 2 q_0 a + q_2 b,      d b = beta g + 2 q_1 b + q_2 a.
+// _lambda_x is computed on .data in the reference (poincare.py:34): a constant here as well.
+template <typename T, class S>
+__device__ __forceinline__ void pb_madd_coef(const S& x2, const S& y2, const S& xy, const Curv& cv, S& A, S& B) {
+    const T c = (T)cv.c;
+    const S den = d_clamp_min(xy * (T(2) * c) + x2 * y2 * (c * c) + T(1), (T)kMinNorm);
+    A = (xy * (T(2) * c) + y2 * c + T(1)) / den;
+    B = (S(T(1)) - x2 * c) / den;
+}
+// which = 0 mobius_add(x = a, y = b), 1 expmap(u = b, p = a), 2 logmap(p1 = a, p2 = b)
+template <typename T, class S>
+__device__ __forceinline__ void pb_map2_coef(int which, const S& a2, const S& b2, const S& ab, const Curv& cv, S& alpha, S& beta) {
+    const T c = (T)cv.c, sc = (T)cv.sc;
+    if (which == 0) {
+        pb_madd_coef<T>(a2, b2, ab, cv, alpha, beta);
+    } else if (which == 1) {
+        const T lam = T(2) / clamp_min(T(1) - c * a2.v, (T)kMinNorm);
+        const S un = d_clamp_min(d_sqrt(b2), (T)kMinNorm);
+        const S F = d_tanh15(un * (sc / T(2) * lam)) / (un * sc);          // second = F * u
+        S A, B;
+        pb_madd_coef<T>(a2, F * F * b2, F * ab, cv, A, B);
+        alpha = A;
+        beta = B * F;
+    } else {
+        const T lam = T(2) / clamp_min(T(1) - c * a2.v, (T)kMinNorm);
+        S A, B;
+        pb_madd_coef<T>(a2, b2, -ab, cv, A, B);                            // sub = (-p1) (+) p2 = -A a + B b
+        const S sn2 = A * A * a2 - A * B * ab * T(2) + B * B * b2;
+        const S sn = d_clamp_min(d_sqrt(sn2), (T)kMinNorm);
+        const S C = d_artanh(sn * sc) * (T(2) / sc / lam) / sn;
+        alpha = -(C * A);
+        beta = C * B;
+    }
+}
+
+template <typename T> struct PbMap2Bwd {
+    Curv cv;
+    int which;
+    const T* b;
+    T* db;
+    // a = saved first operand, g = incoming gradient (left holding d a); the second operand is loaded here, d b stored here
+    template <class TL> __device__ __forceinline__ void operator()(TL& a, TL& g, int64_t row) const {
+        using S = Dual<T, 3>;
+        TL bt;
+        bt.init(a.d);
+        bt.load(b + row * a.d);
+        const T a2 = a.sumsq(), b2 = bt.sumsq(), ab = a.dot(bt), ga = g.dot(a), gb = g.dot(bt);
+        S alpha, beta;
+        // d_sqrt of an exactly zero sum has an infinite slope that the clamp behind it discards; keep it finite
+        pb_map2_coef<T>(which, S::var(a2, 0), S::var(b2 > T(0) ? b2 : T(0), 1), S::var(ab, 2), cv, alpha, beta);
+        T q[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const T da = alpha.d[i], dbt = beta.d[i];
+            q[i] = (da == da && dbt == dbt) ? da * ga + dbt * gb : T(0);
+        }
+#pragma unroll
+        for (int i = 0; i < TL::kRegs; ++i) {
+            const T gi = g.v[i], ai = a.v[i], bi = bt.v[i];
+            g.v[i] = alpha.v * gi + T(2) * q[0] * ai + q[2] * bi;
+            bt.v[i] = beta.v * gi + T(2) * q[1] * bi + q[2] * ai;
+        }
+        bt.store(db + row * a.d);
+    }
+};
+
+// sqdist (ball, :25-31): out = (2 / sc * artanh(sc |(-p1) (+) p2|))^2, one scalar per row; g = its incoming gradient
+template <typename T> struct PbSqdistBwd {
+    Curv cv;
+    const T* g;
+    T* da;
+    template <class TL> __device__ __forceinline__ void operator()(TL& a, TL& bt, int64_t row) const {
+        using S = Dual<T, 3>;
+        const T sc = (T)cv.sc;
+        const T a2 = a.sumsq(), b2 = bt.sumsq(), ab = a.dot(bt);
+        S A, B;
+        pb_madd_coef<T>(S::var(a2, 0), S::var(b2, 1), -S::var(ab, 2), cv, A, B);
+        const S sn2 = A * A * S::var(a2, 0) - A * B * S::var(ab, 2) * T(2) + B * B * S::var(b2, 1);
+        T f[3] = {T(0), T(0), T(0)};
+        if (sn2.v > T(0)) {                                  // torch.norm's gradient at the zero vector is zero
+            const S dist = d_artanh(d_sqrt(sn2) * sc) * (T(2) / sc);
+            const S out = dist * dist;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) f[i] = out.d[i];
+        }
+        const T gs = g[row];
+#pragma unroll
+        for (int i = 0; i < TL::kRegs; ++i) {
+            const T ai = a.v[i], bi = bt.v[i];
+            a.v[i] = gs * (T(2) * f[0] * ai + f[2] * bi);
+            bt.v[i] = gs * (T(2) * f[1] * bi + f[2] * ai);
+        }
+        a.store(da + row * a.d);
+    }
+};
+// sqdist (hyperboloid, :35-41): min(K arcosh(max(-<x, y>_L / K, 1 + eps))^2, 50)
+template <typename T> struct HbSqdistBwd {
+    Curv cv;
+    const T* g;
+    T* da;
+    template <class TL> __device__ __forceinline__ void operator()(TL& x, TL& y, int64_t row) const {
+        using S = Dual<T, 1>;
+        const T K = (T)cv.K;
+        const T x0 = x.first(), y0 = y.first();
+        const S prod = S::var(x.dot(y) - T(2) * x0 * y0, 0);
+        const S theta = d_clamp_min(-prod / K, (T)(1.0 + Lim<T>::hb_eps));
+        const S ac = d_arcosh(theta);
+        const S out = ac * ac * K;
+        const T dprod = (out.v <= T(50) ? out.d[0] : T(0)) * g[row];   // torch.clamp(max=50) passes the gradient up to 50
+        // d prod / d x = y with the time coordinate negated, and vice versa
+#pragma unroll
+        for (int i = 0; i < TL::kRegs; ++i) {
+            const T xi = x.v[i], yi = y.v[i];
+            x.v[i] = dprod * yi;
+            y.v[i] = dprod * xi;
+        }
+        x.set_first(-dprod * y0);
+        y.set_first(-dprod * x0);
+        x.store(da + row * x.d);
+    }
+};
+
 template <typename T, class Op>
 int bwd2(const char* name, const void* saved, const void* grad, void* out, int64_t n, int64_t d, Op op, void* st) {
     return launch_map2<T, int32_t>(name, (const T*)saved, nullptr, (const T*)grad, (T*)out, n, d, op, (hipStream_t)st);
@@ -407,6 +534,22 @@ int bwd2(const char* name, const void* saved, const void* grad, void* out, int64
                                                int fermi_dirac, double r, double t, void* st) {               \
         return launch_edge_decode_bwd<T, true>("hd_hb_edge_decode_bwd_" #sfx, h, pairs, n_rows, gprob, ge, n, d, c, \
                                                fermi_dirac, r, t, st);                                        \
+    }                                                                                                         \
+    extern "C" int hd_pb_map2_bwd_##sfx(int which, const void* a, const void* b, const void* g, void* da,     \
+                                        void* db, int64_t n, int64_t d, hd_curv c, void* st) {                \
+        HD_REQUIRE(which >= 0 && which <= 2, "hd_pb_map2_bwd: map code must be 0 (mobius_add), 1 (expmap) or 2 (logmap)"); \
+        HD_REQUIRE((b && db && db != da) || n == 0, "hd_pb_map2_bwd: second operand / its gradient missing");  \
+        return bwd2<T>("hd_pb_map2_bwd_" #sfx, a, g, da, n, d, PbMap2Bwd<T>{mk(c), which, (const T*)b, (T*)db}, st); \
+    }                                                                                                         \
+    extern "C" int hd_pb_sqdist_bwd_##sfx(const void* a, const void* b, const void* g, void* da, void* db,    \
+                                          int64_t n, int64_t d, hd_curv c, void* st) {                        \
+        HD_REQUIRE((g && da && da != db) || n == 0, "hd_pb_sqdist_bwd: gradient pointers missing");            \
+        return bwd2<T>("hd_pb_sqdist_bwd_" #sfx, a, b, db, n, d, PbSqdistBwd<T>{mk(c), (const T*)g, (T*)da}, st); \
+    }                                                                                                         \
+    extern "C" int hd_hb_sqdist_bwd_##sfx(const void* a, const void* b, const void* g, void* da, void* db,    \
+                                          int64_t n, int64_t d, hd_curv c, void* st) {                        \
+        HD_REQUIRE((g && da && da != db) || n == 0, "hd_hb_sqdist_bwd: gradient pointers missing");            \
+        return bwd2<T>("hd_hb_sqdist_bwd_" #sfx, a, b, db, n, d, HbSqdistBwd<T>{mk(c), (const T*)g, (T*)da}, st); \
     }                                                                                                         \
     extern "C" int hd_rownorm_bwd_add_##sfx(const void* x, const void* coef, const void* g, void* out,       \
                                             int64_t n, int64_t d, void* st) {                                 \

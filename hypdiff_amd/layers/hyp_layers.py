@@ -85,11 +85,11 @@ class HypLinear(nn.Module):
         w = self._weight()
         if not self.use_bias:
             return man.mobius_matvec(w, x, c, _flags=3 if _tangent else 1)
-        if torch.is_grad_enabled() and (w.requires_grad or x.requires_grad):
-            raise NotImplementedError("HypLinear(use_bias=1) has no backward kernels yet (config.py:36 defaults to "
-                                      "bias=0); train with bias=0 or run under torch.no_grad()")
+        # every step below carries its VJP: the row maps and mobius_matvec through their kernels (autograd.py), the
+        # ball's mobius_add through hd_pb_map2_bwd; the hyperboloid's mobius_add (logmap0 -> ptransp0 -> expmap,
+        # manifolds/hyperboloid.py:115-146) is tensor algebra over those, differentiated by torch
         res = man.mobius_matvec(w, x, c, _flags=1)
-        bias = man.proj_tan0(self.bias.detach().view(1, -1), c)
+        bias = man.proj_tan0(self.bias.view(1, -1), c)
         hyp_bias = man.proj(man.expmap0(bias, c), c)
         res = man.proj(man.mobius_add(res, hyp_bias, c=c), c)
         return man.logmap0(res, c) if _tangent else res

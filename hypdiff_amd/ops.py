@@ -96,8 +96,8 @@ def _dev(*ts):
 def _no_grad(*ts):
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts):
         raise NotImplementedError(
-            "this hypdiff_amd op has no backward kernel (autograd covers the denoisers, HypLinear / "
-            "HypAgg / HypAct without bias, and proj / expmap0 / logmap0): call it under torch.no_grad()")
+            "this hypdiff_amd op has no backward kernel (autograd covers the denoisers, HypLinear / HypAgg / HypAct, "
+            "proj / expmap0 / logmap0, mobius_add / expmap / logmap / sqdist): call it under torch.no_grad()")
 
 
 def _stream():
@@ -132,13 +132,19 @@ def map1(name, x, c):
 
 
 def map2(name, a, b, c):
-    """Row-wise binary map; a and b broadcast against each other like torch would."""
-    _dev(a, b); _no_grad(a, b)
+    """Row-wise binary map; a and b broadcast against each other like torch would.  Differentiable w.r.t. both
+    operands (the broadcast is a torch op: a (1, d) bias row gets the sum of its rows' gradients)."""
+    _dev(a, b)
     if a.dtype != b.dtype:
         dt = torch.promote_types(a.dtype, b.dtype)
         a, b = a.to(dt), b.to(dt)
     if a.shape != b.shape:
         a, b = torch.broadcast_tensors(a, b)
+    if torch.is_grad_enabled() and (a.requires_grad or b.requires_grad):
+        from . import autograd as hag
+        if name in hag.RowMap2.CODES:
+            return hag.RowMap2.apply(a, b, name, curv(c))
+    _no_grad(a, b)
     a2, shape = _rows(a)
     b2, _ = _rows(b)
     out = torch.empty_like(a2)
@@ -147,10 +153,15 @@ def map2(name, a, b, c):
 
 
 def sqdist(name, a, b, c):
-    _dev(a, b); _no_grad(a, b)
+    _dev(a, b)
     if a.dtype != b.dtype:
         dt = torch.promote_types(a.dtype, b.dtype)
         a, b = a.to(dt), b.to(dt)
+    if torch.is_grad_enabled() and (a.requires_grad or b.requires_grad):
+        from . import autograd as hag
+        if a.shape != b.shape:
+            a, b = torch.broadcast_tensors(a, b)
+        return hag.SqdistFn.apply(a, b, name, curv(c))
     a2, shape = _rows(a)
     b2, _ = _rows(b)
     out = torch.empty(a2.shape[0], dtype=a2.dtype, device=a2.device)

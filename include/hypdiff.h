@@ -161,6 +161,19 @@ HD_DECL2(hd_hb_agg_tail_bwd, const void* s, const void* dout, void* ds, int64_t 
 HD_DECL2(hd_rownorm_bwd_add, const void* x, const void* coef, const void* g, void* out, int64_t rows, int64_t dim,
          void* stream)
 
+/* VJPs of the ball's two-point maps called on their own (what torch autograd gives for manifolds/poincare.py:25-31,
+ * 55-71, 85-91; _lambda_x is computed on .data there and is a constant here).  Kernel operand order as the forward
+ * entry points: which = 0 mobius_add(x = a, y = b), 1 expmap(u = b, p = a), 2 logmap(p1 = a, p2 = b).  g = d loss / d out
+ * (rows, dim); da, db (rows, dim) receive both gradients in one pass (da may alias g).  hd_*_sqdist_bwd: g (rows,) is
+ * the gradient of the one scalar per row of Manifold.sqdist (poincare.py:25-31, hyperboloid.py:35-41, clamp at 50
+ * included). */
+HD_DECL2(hd_pb_map2_bwd, int which, const void* a, const void* b, const void* g, void* da, void* db, int64_t rows,
+         int64_t dim, hd_curv c, void* stream)
+HD_DECL2(hd_pb_sqdist_bwd, const void* a, const void* b, const void* g, void* da, void* db, int64_t rows, int64_t dim,
+         hd_curv c, void* stream)
+HD_DECL2(hd_hb_sqdist_bwd, const void* a, const void* b, const void* g, void* da, void* db, int64_t rows, int64_t dim,
+         hd_curv c, void* stream)
+
 /* LPModel.decode, models/base_models.py:152-159: sqdist(h[idx[:,0]], h[idx[:,1]]) for int64 index
  * pairs (n_pairs, 2) gathered in the kernel; fermi_dirac != 0 appends FermiDiracDecoder
  * (layers/layers.py:85-87) probs = 1/(exp((sqdist - r)/t) + 1).  out (n_pairs,) */

@@ -525,6 +525,74 @@ def capture_train(out_dir):
     print("train", len(store), "arrays")
 
 
+def capture_train_bias(out_dir):
+    """Gradients the reference's own autograd gives for (1) the HGCN encoder with use_bias = 1
+    (layers/hyp_layers.py:103-107: proj_tan0 -> expmap0 -> proj -> mobius_add -> proj; Hyperboloid:
+    logmap0 -> ptransp0 -> expmap, manifolds/hyperboloid.py:115-146) with NON-zero biases, and (2) the two-point maps of
+    the Poincare ball called on their own (manifolds/poincare.py:25-31, 55-71, 85-91) and Hyperboloid.sqdist (:35-41),
+    for a fixed Gaussian cotangent.  Inputs come from seeded generators; everything needed to replay is stored."""
+    import scipy.sparse as sp
+    import manifolds
+    from utils import data_utils
+    from models.base_models import LPModel
+    store = {}
+    kind, n, dim = "ego", 17, 16
+    adj = gi.synthetic_graph(kind, n)
+    adj_train = data_utils.mask_edges(adj, 0.05, 0.1, 1432)[0]
+    adj_t, feats = data_utils.process(adj_train, sp.eye(n).tocsr(), 1, 1)
+    for mname, c in (("PoincareBall", 0.6), ("Hyperboloid", 1.0)):
+        torch.manual_seed(1432)
+        model = LPModel(lp_args(mname, c, n, n, dim, 1)).train()
+        rs = np.random.RandomState(31)
+        with torch.no_grad():
+            for lyr in model.encoder.layers:
+                lyr.linear.bias.copy_(T((rs.standard_normal(lyr.linear.bias.shape) * 0.1).astype(np.float32)))
+        h = model.encode(feats, adj_t)[0]
+        G = T(np.random.RandomState(99).standard_normal(tuple(h.shape)).astype(np.float32))
+        (h * G).sum().backward()
+        k = f"encoder_bias/{kind}{n}/{mname}/"
+        store[k + "h"], store[k + "G"] = N(h), N(G)
+        for i, lyr in enumerate(model.encoder.layers):
+            store[k + f"W{i}"], store[k + f"b{i}"] = N(lyr.linear.weight), N(lyr.linear.bias)
+            store[k + f"gradW{i}"], store[k + f"gradb{i}"] = N(lyr.linear.weight.grad), N(lyr.linear.bias.grad)
+    ball, hyp = manifolds.PoincareBall(), manifolds.Hyperboloid()
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        for c in (0.6, 1.0):
+            for d in (3, 16, 65):
+                for scale in (0.05, 0.4):
+                    rs = np.random.RandomState(1000 + d)
+                    rows = 9
+                    a = rs.standard_normal((rows, d)); a *= scale * rs.uniform(0.2, 1.0, (rows, 1)) / np.linalg.norm(a, axis=1, keepdims=True) / c ** 0.5
+                    b = rs.standard_normal((rows, d)); b *= scale * rs.uniform(0.2, 1.0, (rows, 1)) / np.linalg.norm(b, axis=1, keepdims=True) / c ** 0.5
+                    g = rs.standard_normal((rows, d))
+                    gs = rs.standard_normal(rows)
+                    k = f"map2/{tag}/c{c}/d{d}/s{scale}/"
+                    store[k + "a"], store[k + "b"], store[k + "g"], store[k + "gs"] = a, b, g, gs
+                    for name, fn in (("mobius_add", lambda x, y: ball.mobius_add(x, y, c)),
+                                     ("expmap", lambda x, y: ball.expmap(y, x, c)),          # u = b, p = a
+                                     ("logmap", lambda x, y: ball.logmap(x, y, c))):
+                        x = T(a, dt).requires_grad_(True)
+                        y = T(b, dt).requires_grad_(True)
+                        out = fn(x, y)
+                        (out * T(g, dt)).sum().backward()
+                        store[k + name + "/out"], store[k + name + "/da"], store[k + name + "/db"] = N(out), N(x.grad), N(y.grad)
+                    x = T(a, dt).requires_grad_(True)
+                    y = T(b, dt).requires_grad_(True)
+                    out = ball.sqdist(x, y, c)
+                    (out * T(gs, dt)).sum().backward()
+                    store[k + "sqdist/out"], store[k + "sqdist/da"], store[k + "sqdist/db"] = N(out), N(x.grad), N(y.grad)
+                    # hyperboloid points: expmap0 of tangent vectors with a zero time coordinate
+                    ha = hyp.expmap0(T(np.concatenate([np.zeros((rows, 1)), a * 3], 1), dt), c).detach()
+                    hb = hyp.expmap0(T(np.concatenate([np.zeros((rows, 1)), b * 3], 1), dt), c).detach()
+                    store[k + "hb/a"], store[k + "hb/b"] = N(ha), N(hb)
+                    x, y = ha.clone().requires_grad_(True), hb.clone().requires_grad_(True)
+                    out = hyp.sqdist(x, y, c)
+                    (out.reshape(-1) * T(gs, dt)).sum().backward()
+                    store[k + "hb/sqdist/out"], store[k + "hb/sqdist/da"], store[k + "hb/sqdist/db"] = N(out), N(x.grad), N(y.grad)
+    np.savez_compressed(os.path.join(out_dir, "train_bias.npz"), **store)
+    print("train_bias", len(store), "arrays")
+
+
 def capture_kmeans(out_dir):
     """HyperbolicKMeans.fit of the reference (hyperkmeans.py:42-44: k=3, max_epochs=5) on embeddings
     inside the unit ball; numpy's global generator is seeded and its two initialisation draws
@@ -688,6 +756,8 @@ def main():
         capture_ddpm_big(out)
     if a.only in ("", "train"):
         capture_train(out)
+    if a.only in ("", "train_bias"):
+        capture_train_bias(out)
     if a.only in ("", "extras"):
         capture_extras(a.out)
     if a.only in ("", "kmeans"):

@@ -110,6 +110,7 @@ def pb_mobius_add(x, y, c):
 def pb_lambda_x(x, c):
     """manifolds/poincare.py:33-35 (no gradient through it in the reference)."""
     c = _c(c)
+    x = x.detach()                      # the reference computes it on x.data: a constant for autograd
     return 2 / torch.clamp(1.0 - c * (x * x).sum(-1, keepdim=True), min=MIN_NORM)
 
 

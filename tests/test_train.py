@@ -11,7 +11,8 @@ import pytest
 import torch
 
 from conftest import assert_close
-from oracle import ddpm as oddpm, diffusion as odiff, golden_inputs as gi
+from oracle import adjacency, ddpm as oddpm, diffusion as odiff, extras as oextras, golden_inputs as gi, layers as olayers
+from oracle import manifolds as om
 
 N_, DIM, K_ = 24, 16, 3
 B, D, Hd, L, Tn = 10, 64, 64, 3, 1000
@@ -534,3 +535,122 @@ def test_hip_dgrad_epilogue_transpose_colsum():
     big = torch.from_numpy(rs.standard_normal((20000, 33)).astype(np.float32)).cuda()
     assert_close(hag.colsum(big).cpu(), big.double().cpu().sum(0), what="colsum big", atol_scale=1e-5,
                  scale=float(big.abs().sum(0).max()))
+
+
+# ---- use_bias = 1 and the two-point maps on their own: the reference's own autograd (tests/golden/train_bias.npz) ----
+MAP2 = [(tag, c, d, s) for tag in ("f32", "f64") for c in (0.6, 1.0) for d in (3, 16, 65) for s in (0.05, 0.4)]
+
+
+def _map2_tol(tag):
+    # gradients of fp32 maps next to cancelling terms (1 - c |x|^2): 2e-5 of the largest gradient entry; fp64: 1e-10
+    return dict(rtol=2e-5, atol_scale=2e-5) if tag == "f32" else dict(rtol=1e-9, atol_scale=1e-10)
+
+
+def test_oracle_two_point_map_grads_vs_reference(golden):
+    """the oracle's autograd (incl. the detached _lambda_x) against the reference's, manifolds/poincare.py:25-31,55-91"""
+    g = golden("train_bias")
+    for tag, c, d, s in MAP2:
+        dt = torch.float32 if tag == "f32" else torch.float64
+        k = f"map2/{tag}/c{c}/d{d}/s{s}/"
+        for name, fn in (("mobius_add", lambda x, y: om.pb_mobius_add(x, y, c)), ("expmap", lambda x, y: om.pb_expmap(y, x, c)),
+                         ("logmap", lambda x, y: om.pb_logmap(x, y, c)), ("sqdist", lambda x, y: om.pb_sqdist(x, y, c))):
+            x = torch.from_numpy(g[k + "a"]).to(dt).requires_grad_(True)
+            y = torch.from_numpy(g[k + "b"]).to(dt).requires_grad_(True)
+            out = fn(x, y)
+            cot = torch.from_numpy(g[k + ("gs" if name == "sqdist" else "g")]).to(dt)
+            (out * cot).sum().backward()
+            tol = dict(rtol=1e-5, atol_scale=2e-6) if tag == "f32" else dict(rtol=1e-10, atol_scale=1e-12)
+            assert_close(out.detach().numpy(), g[k + name + "/out"], what=k + name + " out", **tol)
+            assert_close(x.grad.numpy(), g[k + name + "/da"], what=k + name + " da", **tol)
+            assert_close(y.grad.numpy(), g[k + name + "/db"], what=k + name + " db", **tol)
+        x = torch.from_numpy(g[k + "hb/a"]).requires_grad_(True)
+        y = torch.from_numpy(g[k + "hb/b"]).requires_grad_(True)
+        out = om.hb_sqdist(x, y, c)
+        (out.reshape(-1) * torch.from_numpy(g[k + "gs"]).to(dt)).sum().backward()
+        tol = dict(rtol=1e-5, atol_scale=2e-6) if tag == "f32" else dict(rtol=1e-10, atol_scale=1e-12)
+        assert_close(x.grad.numpy(), g[k + "hb/sqdist/da"], what=k + "hb sqdist da", **tol)
+
+
+def test_oracle_bias_encoder_grads_vs_reference(golden):
+    g = golden("train_bias")
+    kind, n = "ego", 17
+    adj = gi.synthetic_graph(kind, n)
+    import scipy.sparse as sp
+    idx, val, shape = adjacency.process_adj(oextras.mask_edges(adj, 0.05, 0.1, 1432)[0])
+    x = torch.eye(n)
+    for mname, c in (("PoincareBall", 0.6), ("Hyperboloid", 1.0)):
+        k = f"encoder_bias/{kind}{n}/{mname}/"
+        Ws = [torch.from_numpy(g[k + f"W{i}"]).requires_grad_(True) for i in range(2)]
+        bs = [torch.from_numpy(g[k + f"b{i}"]).requires_grad_(True) for i in range(2)]
+        h = olayers.hgcn_encode(mname, x, (torch.from_numpy(idx), torch.from_numpy(val), shape), Ws, [c, c, c], biases=bs)
+        assert_close(h.detach().numpy(), g[k + "h"], what=k + "h", rtol=1e-5, atol_scale=2e-6)
+        (h * torch.from_numpy(g[k + "G"])).sum().backward()
+        for i in range(2):
+            assert_close(Ws[i].grad.numpy(), g[k + f"gradW{i}"], what=k + f"gradW{i}", rtol=2e-5, atol_scale=2e-5)
+            assert_close(bs[i].grad.numpy(), g[k + f"gradb{i}"], what=k + f"gradb{i}", rtol=2e-5, atol_scale=2e-5)
+
+
+@pytest.mark.gpu
+def test_hip_two_point_map_grads_vs_reference(golden):
+    """hd_pb_map2_bwd / hd_{pb,hb}_sqdist_bwd through the drop-in manifold classes and torch autograd"""
+    import hypdiff_amd.manifolds as hm
+    g = golden("train_bias")
+    ball, hyp = hm.PoincareBall(), hm.Hyperboloid()
+    for tag, c, d, s in MAP2:
+        dt = torch.float32 if tag == "f32" else torch.float64
+        k = f"map2/{tag}/c{c}/d{d}/s{s}/"
+        for name, fn in (("mobius_add", lambda x, y: ball.mobius_add(x, y, c)), ("expmap", lambda x, y: ball.expmap(y, x, c)),
+                         ("logmap", lambda x, y: ball.logmap(x, y, c)), ("sqdist", lambda x, y: ball.sqdist(x, y, c))):
+            x = torch.from_numpy(g[k + "a"]).to(dt).cuda().requires_grad_(True)
+            y = torch.from_numpy(g[k + "b"]).to(dt).cuda().requires_grad_(True)
+            out = fn(x, y)
+            cot = torch.from_numpy(g[k + ("gs" if name == "sqdist" else "g")]).to(dt).cuda()
+            (out * cot).sum().backward()
+            assert_close(out.detach().cpu().numpy(), g[k + name + "/out"], what=k + name + " out",
+                         **(dict(rtol=1e-5, atol_scale=2e-6) if tag == "f32" else dict(rtol=1e-10, atol_scale=1e-12)))
+            assert_close(x.grad.cpu().numpy(), g[k + name + "/da"], what=k + name + " da", **_map2_tol(tag))
+            assert_close(y.grad.cpu().numpy(), g[k + name + "/db"], what=k + name + " db", **_map2_tol(tag))
+        x = torch.from_numpy(g[k + "hb/a"]).cuda().requires_grad_(True)
+        y = torch.from_numpy(g[k + "hb/b"]).cuda().requires_grad_(True)
+        out = hyp.sqdist(x, y, c)
+        (out.reshape(-1) * torch.from_numpy(g[k + "gs"]).to(dt).cuda()).sum().backward()
+        assert_close(x.grad.cpu().numpy(), g[k + "hb/sqdist/da"], what=k + "hb sqdist da", **_map2_tol(tag))
+        assert_close(y.grad.cpu().numpy(), g[k + "hb/sqdist/db"], what=k + "hb sqdist db", **_map2_tol(tag))
+    # a (1, d) second operand broadcast over the rows (HypLinear's bias row): its gradient is the sum over rows
+    x = (torch.randn(40, 16, device="cuda") * 0.1).requires_grad_(True)
+    b = (torch.randn(1, 16, device="cuda") * 0.1).requires_grad_(True)
+    ball.mobius_add(x, b, 0.6).square().sum().backward()
+    xr, br = x.detach().cpu().double().requires_grad_(True), b.detach().cpu().double().requires_grad_(True)
+    om.pb_mobius_add(xr, br, 0.6).square().sum().backward()
+    assert_close(b.grad.cpu().numpy(), br.grad.numpy(), what="broadcast bias row grad", rtol=2e-5, atol_scale=2e-5)
+    assert_close(x.grad.cpu().numpy(), xr.grad.numpy(), what="broadcast rows grad", rtol=2e-5, atol_scale=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mname,c", [("PoincareBall", 0.6), ("Hyperboloid", 1.0)])
+def test_hip_bias_encoder_grads_vs_reference(golden, mname, c):
+    """HGCN.encode with use_bias = 1 and non-zero biases: forward and weight / bias gradients for a fixed cotangent against
+    the reference's loss.backward() (layers/hyp_layers.py:103-107)"""
+    import types
+    from hypdiff_amd.models.encoders import HGCN
+    g = golden("train_bias")
+    kind, n, dim = "ego", 17, 16
+    adj = gi.synthetic_graph(kind, n)
+    idx, val, shape = adjacency.process_adj(oextras.mask_edges(adj, 0.05, 0.1, 1432)[0])
+    k = f"encoder_bias/{kind}{n}/{mname}/"
+    feat = n + (1 if mname == "Hyperboloid" else 0)
+    args = types.SimpleNamespace(manifold=mname, c=c, cuda=0, device="cuda:0", feat_dim=feat, dim=dim, num_layers=2,
+                                 act="relu", dropout=0.0, bias=1, use_att=0, local_agg=0)
+    enc = HGCN(torch.tensor([c]).cuda(), args).cuda().train()
+    for i, lyr in enumerate(enc.layers):
+        lyr.linear.load_state_dict({"weight": torch.from_numpy(g[k + f"W{i}"]), "bias": torch.from_numpy(g[k + f"b{i}"])})
+    x = torch.eye(n).cuda()
+    if mname == "Hyperboloid":
+        x = torch.cat([torch.zeros_like(x[:, :1]), x], 1)
+    adj_t = torch.sparse_coo_tensor(torch.from_numpy(idx).cuda(), torch.from_numpy(val).cuda(), shape, check_invariants=False)
+    h = enc.encode(x, adj_t)
+    assert_close(h.detach().cpu().numpy(), g[k + "h"], what=k + "h", rtol=1e-5, atol_scale=2e-6)
+    (h * torch.from_numpy(g[k + "G"]).cuda()).sum().backward()
+    for i, lyr in enumerate(enc.layers):
+        assert_close(lyr.linear.weight.grad.cpu().numpy(), g[k + f"gradW{i}"], what=k + f"gradW{i}", rtol=2e-5, atol_scale=2e-5)
+        assert_close(lyr.linear.bias.grad.cpu().numpy(), g[k + f"gradb{i}"], what=k + f"gradb{i}", rtol=2e-5, atol_scale=2e-5)
