@@ -44,6 +44,12 @@ class Hyperboloid(Manifold):
         return ops.sqdist("hd_hb_sqdist", x, y, c).unsqueeze(-1)
 
     def mobius_matvec(self, m, x, c, _flags=0):  # :120-123
+        if isinstance(x, ops.SparseRows):          # sparse logmap0 rows (first layer, identity features): gather of W^T rows
+            mu = ops.sparse_matvec(x, m)
+            out = torch.empty_like(mu)
+            ops._lib.call("hd_hb_linear_epilogue" + ops._sfx(mu), ops._p(mu), ops._p(out), mu.shape[0], mu.shape[1],
+                          ops.curv(c), _flags, ops._stream())
+            return out
         ops._dev(m, x)
         x2 = self._2d(x).contiguous()
         if torch.is_grad_enabled() and (m.requires_grad or x.requires_grad):

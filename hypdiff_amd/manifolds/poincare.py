@@ -50,6 +50,12 @@ class PoincareBall(Manifold):
     def mobius_matvec(self, m, x, c, _flags=0):  # :93-102
         """x @ m^T on the matrix cores, then the row-norm / tanh / artanh tail in one
         fused row kernel.  `_flags` (internal): 1 = also proj, 2 = then logmap0."""
+        if isinstance(x, ops.SparseRows):          # sparse feature rows (first layer, identity features): gather of W^T rows
+            mx = ops.sparse_matvec(x, m)
+            out = torch.empty_like(mx)
+            ops._lib.call("hd_pb_matvec_epilogue" + ops._sfx(mx), ops._p(mx), ops._p(x.xnorm), ops._p(out), mx.shape[0],
+                          mx.shape[1], ops.curv(c), _flags, ops._stream())
+            return out
         ops._dev(m, x)
         x2, shape = ops._rows(x)
         if torch.is_grad_enabled() and (m.requires_grad or x.requires_grad):

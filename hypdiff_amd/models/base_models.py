@@ -1,6 +1,8 @@
 """Encoder wrapper + link-prediction decoder -- drop-in for the hot-path part of the
 reference's models/base_models.py (`BaseModel.encode` :78-88, `LPModel.decode` :152-159).
 Metrics (sklearn ROC/AP on the host, :169-198) stay outside the accelerated path."""
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -39,7 +41,16 @@ class BaseModel(nn.Module):
     def encode(self, x, adj):
         """:78-88 -> (x, t, h0, adj) with x = h0 = the embeddings"""
         if self.manifold.name == 'Hyperboloid':
-            x = torch.cat([torch.zeros_like(x)[:, 0:1], x], dim=1)
+            # the zero time column (:79-81).  Inference on a persistent feature matrix: the widened copy is kept per
+            # feature tensor, so that caches keyed on the operand (padded copies, sparse feature rows) keep hitting
+            hit = getattr(self, "_time_col_cache", None)
+            if (not torch.is_grad_enabled() and hit is not None and hit[0]() is x
+                    and hit[1] == (x._version, x.data_ptr())):
+                x = hit[2]
+            else:
+                src, x = x, torch.cat([torch.zeros_like(x)[:, 0:1], x], dim=1)
+                if not torch.is_grad_enabled() and x.shape[1] >= ops.SPARSE_ROWS_MIN_WIDTH:
+                    self._time_col_cache = (weakref.ref(src), (src._version, src.data_ptr()), x)
         h = self.encoder.encode(x, adj)
         return h, 1, h, adj
 

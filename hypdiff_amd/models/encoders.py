@@ -66,4 +66,10 @@ class HGCN(Encoder):
         self.encode_graph = True
 
     def encode(self, x, adj):
-        return super(HGCN, self).encode(_lift(self.manifold, x, self.curvatures[0]), adj)
+        c0 = self.curvatures[0]
+        if not torch.is_grad_enabled() and not self.layers[0].linear.use_bias:
+            # identity / one-hot features (utils/data_utils.py:171): the first HypLinear gathers rows of W^T
+            sr = ops.sparse_rows_cached(x, self.manifold, c0, lambda t: _lift(self.manifold, t, c0))
+            if sr is not None:
+                return super(HGCN, self).encode(sr, adj)
+        return super(HGCN, self).encode(_lift(self.manifold, x, c0), adj)

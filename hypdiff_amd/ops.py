@@ -757,6 +757,64 @@ def spmm_into(csr, x, out, col0):
     return out
 
 
+# ---- sparse feature rows: the first HypLinear of a graph with identity / one-hot features ----------------------
+class SparseRows:
+    """The operand rows of a first HypLinear (ball: the lifted features with their row norms; hyperboloid: their
+    logmap0) held as a CSR, because almost every entry is zero: utils/data_utils.py:171 gives Cora / Citeseer
+    identity features of width N, whose lift is one scaled unit vector per row.  x W^T is then a gather of rows of W^T
+    (hd_spmm_csr), not an N x N x d GEMM.  Built once per feature tensor (sparse_rows_cached)."""
+
+    __slots__ = ("csr", "xnorm", "shape", "abi")
+
+    def __init__(self, csr, xnorm, shape, abi):
+        self.csr, self.xnorm, self.shape, self.abi = csr, xnorm, shape, abi
+
+
+SPARSE_ROWS_MIN_WIDTH = 1024         # narrower features: the GEMM is cheap, the dense path stays
+SPARSE_ROWS_MAX_PER_ROW = 8          # mean stored entries per row above which the GEMM wins
+_sparse_rows_cache = {}
+
+
+def sparse_rows_cached(x, manifold, c, lift):
+    """SparseRows of lift(x) for `manifold`, or None when x is not sparse enough.  Inference only; the answer is cached
+    per feature tensor (identity, version, storage) and curvature, so the dense N x K features are read once."""
+    if (torch.is_grad_enabled() and x.requires_grad) or x.dim() != 2 or x.dtype != torch.float32 \
+            or x.shape[1] < SPARSE_ROWS_MIN_WIDTH or x.shape[0] == 0:
+        return None
+    cv = curv(c)
+    key = (id(x), manifold.abi, cv.c)
+    hit = _sparse_rows_cache.get(key)
+    if hit is not None and hit[0]() is x and hit[1] == (x._version, x.data_ptr()):
+        return hit[2]
+    res = None
+    if int(torch.count_nonzero(x)) <= SPARSE_ROWS_MAX_PER_ROW * x.shape[0]:
+        with torch.no_grad():
+            h = lift(x)                                              # proj(expmap0(proj_tan0(x))), dense, once
+            if manifold.abi == "pb":
+                u, xn = h, rownorm(h.contiguous())
+            else:
+                u, xn = map1("hd_hb_logmap0", h, c), None            # the operand of hyperboloid.py:122
+            nz = u != 0
+            counts = nz.sum(1)
+            rowptr = torch.zeros(u.shape[0] + 1, dtype=torch.int32, device=u.device)
+            rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+            col = nz.nonzero()[:, 1].to(torch.int32).contiguous()    # row-major: a row's entries in column order
+            val = u[nz].contiguous()
+            res = SparseRows(CSR(rowptr, col, val, tuple(u.shape)), xn, tuple(u.shape), manifold.abi)
+    if len(_sparse_rows_cache) > 16:
+        _sparse_rows_cache.clear()
+    _sparse_rows_cache[key] = (weakref.ref(x), (x._version, x.data_ptr()), res)
+    return res
+
+
+def sparse_matvec(sr, m):
+    """(sparse operand rows) @ m^T: every output row is the sum of its few stored entries times rows of m^T -- exact
+    for one-hot rows (one product per output element, nothing to sum)."""
+    k = sr.shape[1]
+    mt = transposed_cached(m) if m.shape[1] == k else transposed_cached(m)[:k].contiguous()
+    return spmm(sr.csr, mt)
+
+
 def agg_tail(manifold, s, c_in, c_out=None, act_code=None):
     """proj(expmap0(s)) [+ HypAct] on a stored aggregate s = spmm(adj, xt) (hd_*_agg_tail)."""
     _dev(s)

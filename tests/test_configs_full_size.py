@@ -132,6 +132,52 @@ def test_config4_citation_encode_vs_oracle(gemm_mode, n, m):
     _report(f"config 4: {n} x {n} -> 512", gemm_mode, [("HGCN.encode (PoincareBall)", H(h), want)])
     assert h.shape == (n, dim)
     assert_close(H(h), want, exact=ex, what=f"config 4 encode N={n}")
+    # the encode above took the sparse-feature path (identity features: the first HypLinear gathers rows of W^T);
+    # the dense path -- the K = N GEMM -- must give the same rows: bit for bit on the exact fp32 GEMM (one product per
+    # output element either way), to fp32 rounding on the limb GEMMs
+    from hypdiff_amd import ops
+    pass
+    xg = x.cuda()
+    with torch.no_grad():
+        h_sparse = enc.encode(xg, adj_t)
+        assert any(k[0] == id(xg) for k in ops._sparse_rows_cache)
+        old_w, ops.SPARSE_ROWS_MIN_WIDTH = ops.SPARSE_ROWS_MIN_WIDTH, 1 << 30
+        try:
+            h_dense = enc.encode(xg.clone(), adj_t)
+        finally:
+            ops.SPARSE_ROWS_MIN_WIDTH = old_w
+    assert torch.equal(h_sparse, h)
+    if gemm_mode == "exact":
+        assert torch.equal(h_sparse, h_dense)
+    assert_close(H(h_dense), want, exact=ex, what=f"config 4 encode N={n}, dense first layer")
+
+
+@ALL_MODES
+def test_identity_features_hyperboloid_through_lpmodel(gemm_mode):
+    """LPModel.encode with manifold = Hyperboloid on identity features (N = 1100): the zero time column is prepended
+    (models/base_models.py:79-81), the first HypLinear runs on the sparse logmap0 rows; against the oracle"""
+    from hypdiff_amd import ops, workloads
+    from hypdiff_amd.models.base_models import LPModel
+    n, dim, c = 1100, 256, 1.0
+    adj = workloads.citation_graph(n, 2)
+    idx, val, shape = adjacency.process_adj(adj)
+    args = types.SimpleNamespace(manifold="Hyperboloid", c=c, cuda=0, device="cuda:0", feat_dim=n, n_nodes=n, model="HGCN",
+                                 r=2.0, t=1.0, nb_false_edges=1, nb_edges=1, dim=dim, num_layers=2, act="relu",
+                                 dropout=0.0, bias=0, use_att=0, local_agg=0)
+    torch.manual_seed(21)
+    lp = LPModel(args).cuda().eval()
+    x = torch.eye(n)
+    adj_t = torch.sparse_coo_tensor(torch.from_numpy(idx).cuda(), torch.from_numpy(val).cuda(), shape, check_invariants=False)
+    xg = x.cuda()
+    with torch.no_grad():
+        h = lp.encode(xg, adj_t)[0]
+        h2 = lp.encode(xg, adj_t)[0]                       # second call: the cached widened copy and sparse rows
+    assert torch.equal(h, h2) and len(ops._sparse_rows_cache) >= 1
+    x1 = torch.cat([torch.zeros(n, 1), x], 1)
+    want = _oracle_encode("Hyperboloid", c, x1, idx, val, shape, lp.encoder, torch.float32)
+    ex = _oracle_encode("Hyperboloid", c, x1, idx, val, shape, lp.encoder, torch.float64)
+    _report(f"identity features, Hyperboloid, {n} x {n + 1} -> {dim}", gemm_mode, [("LPModel.encode", H(h), want)])
+    assert_close(H(h), want, exact=ex, what="hyperboloid identity-feature encode")
 
 
 @ALL_MODES
