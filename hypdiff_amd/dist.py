@@ -288,11 +288,15 @@ class DataParallelTrainer:
         launches of a few microseconds: 2.5 ms issued one by one, 1.3 ms of kernels).  Requirements: loss_fn reads
         the same device tensors on every call, draws its random numbers on the device (torch's CUDA generator is
         graph-safe; ddpm.Model does that while a capture is running), never reads anything back to the host; the
-        optimizer is BucketAdam (its step count lives on the device); single process (no collective in the graph).
+        optimizer is BucketAdam (its step count lives on the device).  With more than one rank (backend nccl = RCCL) the
+        chunked gradient all-reduces are recorded into the graph as well -- they are stream operations -- so the graphed
+        step survives data parallelism (every rank must capture and replay in lockstep).
         `warmup` eager steps run first on a side stream (allocations, caches).  The parameters' versions are bumped
         after every replay, as after an eager step."""
-        if _collective(self.group):
-            raise NotImplementedError("DataParallelTrainer.capture: single-process steps only")
+        coll = _collective(self.group)
+        if coll and dist.get_backend(self.group) != "nccl":
+            raise NotImplementedError("DataParallelTrainer.capture with more than one rank needs the nccl (RCCL) backend: "
+                                      "its collectives are stream operations and can be recorded into the graph")
         if not isinstance(self.opt, BucketAdam):
             raise TypeError("DataParallelTrainer.capture needs the BucketAdam optimizer (device-side step count)")
         side = torch.cuda.Stream()
@@ -303,7 +307,9 @@ class DataParallelTrainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # with collectives in the step RCCL's watchdog thread polls events while the capture is open: thread-local
+        # capture mode keeps its calls from invalidating the capture
+        with torch.cuda.graph(graph, capture_error_mode="thread_local" if coll else "global"):
             loss = self.step(loss_fn)
         params = self.bucket.params
 

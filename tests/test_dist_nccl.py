@@ -111,6 +111,31 @@ def _worker(port, q):
                 slabs = hdist.sharded_hgcn_encode(enc, xin, sh, n_slabs=4)
             res["gather_" + mname] = bool(torch.equal(whole, full))
             res["slabs_" + mname] = bool(torch.equal(slabs, full))
+        # (4) the whole training step WITH its gradient all-reduces as one HIP graph (DataParallelTrainer.capture):
+        #     replays == eager steps, bit for bit
+        try:
+            torch.manual_seed(5)
+            import copy as _copy
+            from hypdiff_amd.models.direction_diffusion import diffusion as _diffusion
+            dg = _diffusion(types.SimpleNamespace(r=2.0, t=1.0), dim, num_timesteps=200).train()
+            de = _diffusion(types.SimpleNamespace(r=2.0, t=1.0), dim, num_timesteps=200).train()
+            de.mlp.load_state_dict(dg.mlp.state_dict())
+            emb_d = torch.from_numpy(emb).to(dev)
+            lab_d = labels
+            mk = lambda dd: (lambda: dd(emb_d, None, lab_d, u0, restrict=True, graphset=True, t=t, noise=noise.clone()))
+            trg = hdist.DataParallelTrainer(dg.mlp, lr=1e-3)
+            tre = hdist.DataParallelTrainer(de.mlp, lr=1e-3)
+            replay = trg.capture(mk(dg), warmup=2)
+            for _ in range(3):
+                replay()
+            for _ in range(2 + 3):
+                tre.step(mk(de))
+            torch.cuda.synchronize()
+            res["graphed_step_with_collectives"] = all(torch.equal(a.detach(), b.detach())
+                                                       for a, b in zip(dg.mlp.parameters(), de.mlp.parameters()))
+        except Exception:
+            import traceback
+            res["graphed_step_with_collectives_error"] = traceback.format_exc()[-1500:]
         torch.cuda.synchronize()
         dist.destroy_process_group()
     except Exception as e:          # report instead of hanging the parent
@@ -129,4 +154,5 @@ def test_rccl_world_of_one():
     assert "error" not in res, res["error"]
     assert p.exitcode == 0
     assert res.pop("chunks") >= 1
+    assert "graphed_step_with_collectives_error" not in res, res["graphed_step_with_collectives_error"]
     assert all(res.values()), res
