@@ -8,7 +8,8 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhypdiff_hip.so")
+# HD_LIB_PATH: another build of the same library (kernel experiments, tools/probes); never a different implementation
+LIB_PATH = os.environ.get("HD_LIB_PATH") or os.path.join(_HERE, "libhypdiff_hip.so")
 
 
 class HdCurv(ctypes.Structure):

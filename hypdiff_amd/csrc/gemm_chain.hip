@@ -144,6 +144,20 @@ __device__ __forceinline__ bool dep_ready(const ChainArgs& P, const int* tab, in
     return ld_agent(P.ws + WS_DONE + (l - 1) * P.tiles_m + rb) >= (unsigned)tab[kMaxLayers + l];
 }
 
+// SCHED (compile time, -DHD_CHAIN_SCHED): how the nine staging pieces of a wavefront are issued relative to its 48 MFMAs
+// of the slab.  0 = all nine, then the MFMAs; 1, 2 = dealt between the eight accumulators' MFMA groups (kPieces).  The
+// in-kernel phase probe (-DHD_CHAIN_PHASE_PROBE, tools/probes/chain_stamps.py) shows wave 0 spending ~40 % of a slab
+// issuing the nine pieces, but dealing them between the MFMAs is SLOWER (the wave then stalls inside its MFMA stream while
+// its partner workgroup is stalled the same way); timing experiments (-DHD_CHAIN_EXPERIMENT) put the floor of the
+// staging + barrier + fragment-read pipeline at ~420 us of the 500: the loop is bound by that pipeline, not by the MFMAs.
+__device__ constexpr int kPieces[3][8] = {{9, 0, 0, 0, 0, 0, 0, 0}, {2, 2, 2, 2, 1, 0, 0, 0}, {2, 1, 1, 1, 1, 1, 1, 1}};
+#ifndef HD_CHAIN_EXPERIMENT
+#define HD_CHAIN_EXPERIMENT 0      // timing experiments only (results are wrong): 1 = two staging pieces of nine,
+#endif                             // 2 = 8 MFMAs of 48, 3 = 6 fragment reads of 18
+#ifndef HD_CHAIN_SCHED
+#define HD_CHAIN_SCHED 0           // measured: 0 = 501 us, 1 = 523 us, 2 = 551 us per chain (same box)
+#endif
+constexpr int SCHED = HD_CHAIN_SCHED;
 __global__ __launch_bounds__(256) void mlp_chain(const ChainArgs P) {
     __shared__ uint4 lds[CH_BUF];
     __shared__ int nxt_s[8];                                  // successor: {queue, index, ready, layer, row block, column tile}
@@ -272,15 +286,23 @@ __global__ __launch_bounds__(256) void mlp_chain(const ChainArgs P) {
             const bool async = nslab >= 5 && !(P.flags & 4);
             const int t_poll = nslab - 3, t_pull = nslab - 5;
             const uint4 *a_n = nullptr, *w_n = nullptr;
+#ifdef HD_CHAIN_PHASE_PROBE
+            unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, pt = wall_clock64(), pn;
+#define HD_PH(k) { pn = wall_clock64(); ph[k] += pn - pt; pt = pn; }
+#else
+#define HD_PH(k)
+#endif
             for (int t = 0; t < nslab; ++t) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                HD_PH(0)
                 if (async && t == t_poll + 2 && tid == 0) {    // hand the successor to the other wavefronts
                     nxt_s[0] = curq; nxt_s[1] = p_idx; nxt_s[2] = p_ready; nxt_s[3] = p_l; nxt_s[4] = p_rb; nxt_s[5] = p_tn;
                 }
                 __builtin_amdgcn_s_barrier();                   // slab t has landed; every wave's older stores are done
+                HD_PH(1)
                 uint4 fa[4][3], fw[2][3];
 #pragma unroll
-                for (int li = 0; li < 3; ++li) {
+                for (int li = 0; li < (HD_CHAIN_EXPERIMENT == 3 ? 1 : 3); ++li) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) fa[i][li] = lds[a_off + li * 4 * 128 + i * 16];
 #pragma unroll
@@ -295,7 +317,18 @@ __global__ __launch_bounds__(256) void mlp_chain(const ChainArgs P) {
                     ntn_ = __builtin_amdgcn_readfirstlane(nxt_s[5]);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (HD_CHAIN_EXPERIMENT == 3) {
+#pragma unroll
+                    for (int li = 1; li < 3; ++li) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) fa[i][li] = fa[i][0];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) fw[j][li] = fw[j][0];
+                    }
+                }
+                HD_PH(2)
                 __builtin_amdgcn_s_barrier();                   // every wave holds its fragments: the buffer is free
+                HD_PH(3)
                 // Thread 0's step of the successor protocol, on the four slabs that have one (a scalar test elsewhere).
                 // Nothing may sit between the vmcnt(0) at the top of a slab and its fragment reads, and nothing may delay
                 // this slab's staging loads: the value the previous step left in flight is taken over (one move, after
@@ -304,12 +337,12 @@ __global__ __launch_bounds__(256) void mlp_chain(const ChainArgs P) {
                 const bool act = async && (t == t_pull || t == t_pull + 1 || t == t_poll || t == t_poll + 1);
                 unsigned got = 0;
                 if (act && tid == 0) asm volatile("v_mov_b32 %0, %1" : "=v"(got) : "v"(pend));
-                if (t + 1 < nslab) {
-                    HD_STAGE(a_cur, w_cur, t + 1)
-                } else if (nidx_ >= 0 && nready_) {
-                    a_n = a_src(nl_, nrb_); w_n = w_src(nl_, ntn_);
-                    HD_STAGE(a_n, w_n, 0)
-                }
+                // where the next slab comes from: this tile's next slab, or the successor's first (none: nothing is staged)
+                const bool more = t + 1 < nslab;
+                const bool do_stage = more || (nidx_ >= 0 && nready_);
+                if (!more && do_stage) { a_n = a_src(nl_, nrb_); w_n = w_src(nl_, ntn_); }
+                const uint4* const sa = more ? a_cur + (size_t)(t + 1) * kTile : a_n;
+                const uint4* const sw = more ? w_cur + (size_t)(t + 1) * kTile : w_n;
                 if (t == 0 && done_l >= 0) {
                     // the previous tile's image stores were complete in every wavefront at this slab's first barrier (each
                     // waited vmcnt(0) before it): raise its row block's counter
@@ -344,18 +377,43 @@ __global__ __launch_bounds__(256) void mlp_chain(const ChainArgs P) {
                     }
                     if (addr) pend = __hip_atomic_fetch_add(addr, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        f32x4 c = acc[i][j];
+                HD_PH(4)
 #define HD_MM(wl, al) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[j][wl]), \
                                                                   __builtin_bit_cast(bf16x8, fa[i][al]), c, 0, 0, 0);
-                        HD_MM(0, 2) HD_MM(2, 0) HD_MM(1, 1) HD_MM(0, 1) HD_MM(1, 0) HD_MM(0, 0)
+#define HD_SLAB                                                                                                  \
+    {                                                                                                            \
+        int piece_no = 0;                                                                                        \
+        _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                                          \
+            const int i = g >> 1, j = g & 1;                                                                     \
+            if (kPieces[SCHED][g] > 0 && do_stage) {                                                             \
+                _Pragma("unroll") for (int u = 0; u < kPieces[SCHED][g]; ++u, ++piece_no) {                      \
+                    if (HD_CHAIN_EXPERIMENT == 1 && piece_no != 0 && piece_no != QA) continue;                   \
+                    if (piece_no < QA) {                                                                         \
+                        const int piece = piece_no * 4 + wave;                                                   \
+                        glds16(sa + piece * 64, lds + piece * 64);                                               \
+                    } else {                                                                                     \
+                        const int piece = (piece_no - QA) * 4 + wave;                                            \
+                        glds16(sw + piece * 128, lds + CH_A + piece * 64);                                       \
+                    }                                                                                            \
+                }                                                                                                \
+            }                                                                                                    \
+            if (SCHED) __builtin_amdgcn_sched_barrier(0);                                                        \
+            f32x4 c = acc[i][j];                                                                                 \
+            if (HD_CHAIN_EXPERIMENT != 2) { HD_MM(0, 2) HD_MM(2, 0) HD_MM(1, 1) HD_MM(0, 1) HD_MM(1, 0) }        \
+            HD_MM(0, 0)                                                                                          \
+            acc[i][j] = c;                                                                                       \
+            if (SCHED) __builtin_amdgcn_sched_barrier(0);                                                        \
+        }                                                                                                        \
+    }
+                HD_SLAB
+#undef HD_SLAB
 #undef HD_MM
-                        acc[i][j] = c;
-                    }
             }
+            HD_PH(5)
+#ifdef HD_CHAIN_PHASE_PROBE
+            if (P.dbg && tid == 0)
+                for (int k = 0; k < 6; ++k) P.dbg[512 * 8 + 512 * 24 * 4 + (size_t)blockIdx.x * 8 + k] += ph[k];
+#endif
             if (!stamped) HD_STAMP(2)
             if (P.dbg && tid == 0 && seq < 24) {
                 unsigned long long* e = P.dbg + 512 * 8 + ((size_t)blockIdx.x * 24 + seq) * 4;
@@ -596,14 +654,19 @@ extern "C" int hd_mlp_chain_limbs_f32(const void* A0, int64_t rows, const hd_mlp
     const size_t static_lds = CH_BUF * 16 + 64;
     const size_t want = per_cu == 3 ? 0 : (per_cu == 2 ? 56 * 1024 : 100 * 1024);
     const size_t pad = want > static_lds ? want - static_lds : 0;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};                  // per device: the attribute belongs to the device's code object
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        set_error("hd_mlp_chain_limbs_f32: no current device");
+        return HD_EHIP;
+    }
+    if (!attr_set[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 100 * 1024) != hipSuccess) {
             set_error("hd_mlp_chain_limbs_f32: hipFuncSetAttribute failed");
             return HD_EHIP;
         }
-        attr_set = true;
+        attr_set[dev] = true;
     }
     mlp_chain<<<dim3((unsigned)grid), dim3(256), pad, (hipStream_t)st>>>(P);
     return check_launch("hd_mlp_chain_limbs_f32");
