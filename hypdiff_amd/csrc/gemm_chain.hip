@@ -59,9 +59,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMaxLayers = 8;
 constexpr int kTile = 4 * 3 * 128;               // 16-byte chunks of one (row block, K slab) tile of a limb image
-constexpr int BNT = 64;                          // tile 128 x 64, 2 x 2 wavefronts of 64 x 32
+constexpr int BNT = 128;                         // wide tile 128 x 128, 2 x 2 wavefronts of 64 x 64; narrow tile 128 x 64
+constexpr int NJ = BNT / 32;                     // 16-column accumulators per wavefront and 16-row group (wide tile)
 constexpr int CH_A = 4 * 3 * 128, CH_W = 4 * 3 * BNT, CH_BUF = CH_A + CH_W;
-constexpr int QA = 6, QW = 3;                    // 1 KiB LDS-DMA pieces per wavefront and slab
+constexpr int QA = 6, QW = 6;                    // 1 KiB LDS-DMA pieces per wavefront and slab (narrow tile: W pieces of two wavefronts only)
 // workspace words (unsigned): queue head q at q * 32 (a 128-byte line each), then fail, exited, then the counters
 constexpr int WS_FAIL = 256, WS_EXITED = 257, WS_STAT = 260, WS_EXIT_GROUP = 288, WS_DONE = 288 + 256;   // WS_STAT..+3: slow paths, polls that failed (flag 8)
 constexpr uint64_t kTimeoutTicks = 200000000ull; // 2 s of the 100 MHz wall clock
@@ -72,6 +73,7 @@ struct Layer {
     uint4* out_img;          // limb image of the output (M, N), or null
     float* out_f32;          // fp32 output (M, N) with row pitch ldc, or null
     int N, nslab, tiles_n, nslab_out, epi, ldc;
+    int wide;                // 1: column tiles of 128 (the last one narrow when <= 64 columns are left); 0: all tiles 64 wide
 };
 struct ChainArgs {
     Layer L[kMaxLayers];
@@ -103,9 +105,12 @@ __device__ __forceinline__ void glds16(const uint4* g, uint4* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
-// 16-byte write-through store (sc1): the bytes are in memory, not in this XCD's L2, once vmcnt has counted it
+// 16-byte write-through store (sc1): the bytes are in memory, not in this XCD's L2, once vmcnt has counted it.
+// The s_nop belongs to the store: a VALU write of the data registers needs a wait state after a store of more than 8
+// bytes, and the compiler's hazard recogniser does not see into inline assembly (measured: without it the 128-wide
+// build returned a wrong accumulator register in lanes 12-15 of every row in 143 of 150 launches).
 __device__ __forceinline__ void store16_sc1(uint4* p, u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 // lanes L (even 16-lane row) and L + 16 (odd row) hold halves (a, b) of two different chunks; afterwards the even row
 // holds both halves of its chunk in (a, b) and the odd row both halves of its own: v_permlane16_swap exchanges the
@@ -144,28 +149,22 @@ __device__ __forceinline__ bool dep_ready(const ChainArgs& P, const int* tab, in
     return ld_agent(P.ws + WS_DONE + (l - 1) * P.tiles_m + rb) >= (unsigned)tab[kMaxLayers + l];
 }
 
-// SCHED (compile time, -DHD_CHAIN_SCHED): how the nine staging pieces of a wavefront are issued relative to its 48 MFMAs
-// of the slab.  0 = all nine, then the MFMAs; 1, 2 = dealt between the eight accumulators' MFMA groups (kPieces).  The
-// in-kernel phase probe (-DHD_CHAIN_PHASE_PROBE, tools/probes/chain_stamps.py) shows wave 0 spending ~40 % of a slab
-// issuing the nine pieces, but dealing them between the MFMAs is SLOWER (the wave then stalls inside its MFMA stream while
-// its partner workgroup is stalled the same way); timing experiments (-DHD_CHAIN_EXPERIMENT) put the floor of the
-// staging + barrier + fragment-read pipeline at ~420 us of the 500: the loop is bound by that pipeline, not by the MFMAs.
-__device__ constexpr int kPieces[3][8] = {{9, 0, 0, 0, 0, 0, 0, 0}, {2, 2, 2, 2, 1, 0, 0, 0}, {2, 1, 1, 1, 1, 1, 1, 1}};
+// Measured and not kept (same box, 501 us per chain as it is): the nine staging pieces of a wavefront dealt between the
+// MFMA groups of the slab instead of issued ahead of them -- 523 us (two pieces ahead of each of the first groups) and 551 us
+// (one per group): the in-kernel phase probe (-DHD_CHAIN_PHASE_PROBE, tools/probes/chain_stamps.py) has wave 0 spend ~40 %
+// of a slab issuing the pieces, but a wave stalled on a piece inside its MFMA stream only lands the slab later.  Timing
+// experiments (-DHD_CHAIN_EXPERIMENT) put the staging + barrier + fragment-read pipeline alone at ~420 us of the 500.
 #ifndef HD_CHAIN_EXPERIMENT
 #define HD_CHAIN_EXPERIMENT 0      // timing experiments only (results are wrong): 1 = two staging pieces of nine,
 #endif                             // 2 = 8 MFMAs of 48, 3 = 6 fragment reads of 18
-#ifndef HD_CHAIN_SCHED
-#define HD_CHAIN_SCHED 0           // measured: 0 = 501 us, 1 = 523 us, 2 = 551 us per chain (same box)
-#endif
-constexpr int SCHED = HD_CHAIN_SCHED;
-__global__ __launch_bounds__(256) void mlp_chain(const ChainArgs P) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void mlp_chain(const ChainArgs P) {
     __shared__ uint4 lds[CH_BUF];
     __shared__ int nxt_s[8];                                  // successor: {queue, index, ready, layer, row block, column tile}
     __shared__ int tab[2 * kMaxLayers + 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int r16 = lane & 15, kq = lane >> 4;
-    const int a_off = kq * 128 + wr * 64 + r16, w_off = CH_A + kq * BNT + wc * 32 + r16;
+    const int a_off = kq * 128 + wr * 64 + r16;
     unsigned* const ws = P.ws;
     const int M = P.M, tiles_m = P.tiles_m;
     // HW_REG_XCC_ID (id 20), bits 3:0: the XCD this workgroup runs on; locality only, never correctness
@@ -236,24 +235,34 @@ __global__ __launch_bounds__(256) void mlp_chain(const ChainArgs P) {
     (void)seq;
     int done_l = -1, done_rb = 0;                             // finished tile whose counter add is still owed
 
-#define HD_STAGE(as_, ws_, t)                                                               \
+    // Tile kinds: 0 = wide (128 x 128, a wavefront 64 x 64); 1 / 2 = narrow (128 x 64, a wavefront 64 x 32) on rows
+    // 0..63 / 64..127 of a 128-row block of the W image.  A narrow tile needs only the W pieces of that half -- piece
+    // parity = wavefront parity, so two wavefronts stage W and two do not -- half the fragments and half the MFMAs.
+    // Narrow tiles are the last column tile of a wide layer when at most 64 columns are left, and every tile of a layer
+    // the host marks narrow (the last layer when it has too few wide tiles to fill the chip evenly at the end).
+#define HD_STAGE(as_, ws_, t, kind_)                                                        \
     {                                                                                       \
         const uint4* as = (as_) + (size_t)(t) * kTile;                                      \
         const uint4* wsrc = (ws_) + (size_t)(t) * kTile;                                    \
         _Pragma("unroll") for (int q = 0; q < QA; ++q) {                                    \
+            if (HD_CHAIN_EXPERIMENT == 1 && q) continue;                                    \
             const int piece = q * 4 + wave;                                                 \
             glds16(as + piece * 64, lds + piece * 64);                                      \
         }                                                                                   \
-        _Pragma("unroll") for (int q = 0; q < QW; ++q) {                                    \
-            const int piece = q * 4 + wave;                                                 \
-            glds16(wsrc + piece * 128, lds + CH_A + piece * 64);                            \
+        if ((kind_) == 0 || ((kind_) - 1) == (wave & 1)) {                                  \
+            _Pragma("unroll") for (int q = 0; q < QW; ++q) {                                \
+                if (HD_CHAIN_EXPERIMENT == 1 && q) continue;                                \
+                const int piece = q * 4 + wave;                                             \
+                glds16(wsrc + piece * 64, lds + CH_A + piece * 64);                         \
+            }                                                                               \
         }                                                                                   \
     }
+    auto tile_kind = [&](int l, int tn) { return P.L[l].wide ? (P.L[l].N - tn * BNT <= 64 ? 1 : 0) : 1 + (tn & 1); };
     auto a_src = [&](int l, int rb) {
         const uint4* base = l == 0 ? P.A0 : P.L[l - 1].out_img;
         return base + (size_t)rb * P.L[l].nslab * kTile + lane;
     };
-    auto w_src = [&](int l, int tn) { return P.L[l].W + (size_t)(tn >> 1) * P.L[l].nslab * kTile + (tn & 1) * 64 + lane; };
+    auto w_src = [&](int l, int tn) { return P.L[l].W + (size_t)(P.L[l].wide ? tn : tn >> 1) * P.L[l].nslab * kTile + lane; };
 
     HD_STAMP(1)
     int stamped = 0;
@@ -262,16 +271,19 @@ __global__ __launch_bounds__(256) void mlp_chain(const ChainArgs P) {
         decode(tab, P.n_layers, tiles_m, cq, cidx, l, rb, tn);
         l = __builtin_amdgcn_readfirstlane(l); rb = __builtin_amdgcn_readfirstlane(rb); tn = __builtin_amdgcn_readfirstlane(tn);
         const uint4 *a_cur = a_src(l, rb), *w_cur = w_src(l, tn);
-        HD_STAGE(a_cur, w_cur, 0)
+        int kind = tile_kind(l, tn);
+        HD_STAGE(a_cur, w_cur, 0, kind)
         for (;;) {
             const Layer& Ly = P.L[l];
             const int nslab = Ly.nslab;
+            const bool narrow = kind != 0;
+            const int w_off = CH_A + kq * BNT + (narrow ? (kind - 1) * 64 + wc * 32 : wc * 64) + r16;
             const unsigned long long tile_t0 = P.dbg ? wall_clock64() : 0ull;
-            f32x4 acc[4][2];
+            f32x4 acc[4][NJ];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
             // successor, fetched asynchronously by thread 0 while this tile multiplies (nslab >= 4)
@@ -300,13 +312,17 @@ __global__ __launch_bounds__(256) void mlp_chain(const ChainArgs P) {
                 }
                 __builtin_amdgcn_s_barrier();                   // slab t has landed; every wave's older stores are done
                 HD_PH(1)
-                uint4 fa[4][3], fw[2][3];
+                uint4 fa[4][3], fw[NJ][3];
 #pragma unroll
                 for (int li = 0; li < (HD_CHAIN_EXPERIMENT == 3 ? 1 : 3); ++li) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) fa[i][li] = lds[a_off + li * 4 * 128 + i * 16];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) fw[j][li] = lds[w_off + li * 4 * BNT + j * 16];
+                    if (NJ == 4 && !narrow) {
+#pragma unroll
+                        for (int j = 2; j < NJ; ++j) fw[j][li] = lds[w_off + li * 4 * BNT + j * 16];
+                    }
                 }
                 if (async && t == t_poll + 2) {
                     nq_ = __builtin_amdgcn_readfirstlane(nxt_s[0]);
@@ -323,7 +339,7 @@ __global__ __launch_bounds__(256) void mlp_chain(const ChainArgs P) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) fa[i][li] = fa[i][0];
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) fw[j][li] = fw[j][0];
+                        for (int j = 0; j < NJ; ++j) fw[j][li] = fw[j][0];
                     }
                 }
                 HD_PH(2)
@@ -380,33 +396,21 @@ __global__ __launch_bounds__(256) void mlp_chain(const ChainArgs P) {
                 HD_PH(4)
 #define HD_MM(wl, al) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[j][wl]), \
                                                                   __builtin_bit_cast(bf16x8, fa[i][al]), c, 0, 0, 0);
-#define HD_SLAB                                                                                                  \
-    {                                                                                                            \
-        int piece_no = 0;                                                                                        \
-        _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                                          \
-            const int i = g >> 1, j = g & 1;                                                                     \
-            if (kPieces[SCHED][g] > 0 && do_stage) {                                                             \
-                _Pragma("unroll") for (int u = 0; u < kPieces[SCHED][g]; ++u, ++piece_no) {                      \
-                    if (HD_CHAIN_EXPERIMENT == 1 && piece_no != 0 && piece_no != QA) continue;                   \
-                    if (piece_no < QA) {                                                                         \
-                        const int piece = piece_no * 4 + wave;                                                   \
-                        glds16(sa + piece * 64, lds + piece * 64);                                               \
-                    } else {                                                                                     \
-                        const int piece = (piece_no - QA) * 4 + wave;                                            \
-                        glds16(sw + piece * 128, lds + CH_A + piece * 64);                                       \
-                    }                                                                                            \
-                }                                                                                                \
-            }                                                                                                    \
-            if (SCHED) __builtin_amdgcn_sched_barrier(0);                                                        \
-            f32x4 c = acc[i][j];                                                                                 \
-            if (HD_CHAIN_EXPERIMENT != 2) { HD_MM(0, 2) HD_MM(2, 0) HD_MM(1, 1) HD_MM(0, 1) HD_MM(1, 0) }        \
-            HD_MM(0, 0)                                                                                          \
-            acc[i][j] = c;                                                                                       \
-            if (SCHED) __builtin_amdgcn_sched_barrier(0);                                                        \
-        }                                                                                                        \
-    }
-                HD_SLAB
-#undef HD_SLAB
+                if (do_stage) {
+                    const int kind_next = more ? kind : tile_kind(nl_, ntn_);
+                    HD_STAGE(sa, sw, 0, kind_next)
+                }
+#define HD_MMS(J0, J1)                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
+            _Pragma("unroll") for (int j = J0; j < J1; ++j) {                                                    \
+                f32x4 c = acc[i][j];                                                                             \
+                if (HD_CHAIN_EXPERIMENT != 2) { HD_MM(0, 2) HD_MM(2, 0) HD_MM(1, 1) HD_MM(0, 1) HD_MM(1, 0) }    \
+                HD_MM(0, 0)                                                                                      \
+                acc[i][j] = c;                                                                                   \
+            }
+                HD_MMS(0, 2)
+                if (NJ == 4 && !narrow) { HD_MMS(2, NJ) }
+#undef HD_MMS
 #undef HD_MM
             }
             HD_PH(5)
@@ -421,68 +425,73 @@ __global__ __launch_bounds__(256) void mlp_chain(const ChainArgs P) {
             }
             // ---- write-out of the C^T tile: a lane owns row m and columns nb .. nb + 3 of accumulator (i, j) ----
             {
-                const int m0 = rb * 128, n0 = tn * BNT + wc * 32;
+                const int m0 = rb * 128, n0 = Ly.wide ? tn * BNT + (narrow ? wc * 32 : wc * 64) : tn * 64 + wc * 32;
                 const int N = Ly.N, epi = Ly.epi, ldc = Ly.ldc;
                 const float* __restrict__ bias = Ly.bias;
                 uint4* __restrict__ CL = Ly.out_img;
                 float* __restrict__ C = Ly.out_f32;
                 const bool vec = (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
-                float bq[2][4];
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int n = n0 + j * 16 + 4 * kq + e;
-                        bq[j][e] = (bias && n < N) ? bias[n] : 0.f;
-                    }
-                // the wavefront's 32 columns are exactly K slab `so` of the output image
-                const int so = n0 >> 5;
-                const bool img = CL != nullptr && so < Ly.nslab_out;
-                // this lane's chunk after the pair swap: even 16-lane rows keep accumulator j = 0 (chunk kc = kq / 2),
-                // odd rows j = 1 (kc = 2 + kq / 2)
+                // this lane's chunk after the pair swap: even 16-lane rows keep the even accumulator of a pair (chunk
+                // kc = kq / 2), odd rows the odd one (kc = 2 + kq / 2)
                 const int kc_mine = (kq & 1) * 2 + (kq >> 1);
-                uint4* const cl_base = img ? CL + ((size_t)rb * Ly.nslab_out + so) * kTile + kc_mine * 128 : nullptr;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int mloc = wr * 64 + i * 16 + r16;
-                    const int m = m0 + mloc;
-                    const bool row_ok = m < M;
-                    float v[2][4];
+                for (int jp = 0; jp < NJ / 2; ++jp) {
+                    if (jp && narrow) continue;
+                    // the pair's 32 columns are exactly K slab `so` of the output image
+                    const int nq = n0 + jp * 32;
+                    const int so = nq >> 5;
+                    const bool img = CL != nullptr && so < Ly.nslab_out;
+                    uint4* const cl_base = img ? CL + ((size_t)rb * Ly.nslab_out + so) * kTile + kc_mine * 128 : nullptr;
+                    float bq[2][4];
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float x = acc[i][j][e] + bq[j][e];
-                            if (epi == 1) x = gelu_erfc(x);
-                            // columns past N are the zero padding of the next layer's K; rows past M are written as zeros
-                            v[j][e] = (row_ok && n0 + j * 16 + 4 * kq + e < N) ? x : 0.f;
+                            const int n = nq + j * 16 + 4 * kq + e;
+                            bq[j][e] = (bias && n < N) ? bias[n] : 0.f;
                         }
-                    if (img) {
-                        u32x2 h0, m0_, l0, h1, m1, l1;
-                        split4(v[0], h0, m0_, l0);
-                        split4(v[1], h1, m1, l1);
-                        pair_swap(h0, h1);
-                        pair_swap(m0_, m1);
-                        pair_swap(l0, l1);
-                        // even rows now hold {own j = 0 half, partner's j = 0 half} in (x0, x1); odd rows {partner's j = 1
-                        // half, own j = 1 half}: in both cases (first, second) = columns (8 kc .. + 3, + 4 .. + 7)
-                        uint4* o = cl_base + mloc;
-                        store16_sc1(o, u32x4{h0.x, h0.y, h1.x, h1.y});
-                        store16_sc1(o + 4 * 128, u32x4{m0_.x, m0_.y, m1.x, m1.y});
-                        store16_sc1(o + 8 * 128, u32x4{l0.x, l0.y, l1.x, l1.y});
-                    }
-                    if (C && row_ok) {
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const int nb = n0 + j * 16 + 4 * kq;
-                            float* o = C + (size_t)m * ldc + nb;
-                            if (vec && nb + 3 < N) {
-                                // write-through as well: nothing of this launch is left dirty in the L2s when it ends
-                                store16_sc1(reinterpret_cast<uint4*>(o), __builtin_bit_cast(u32x4, f32x4{v[j][0], v[j][1], v[j][2], v[j][3]}));
-                            } else {
+                    for (int i = 0; i < 4; ++i) {
+                        const int mloc = wr * 64 + i * 16 + r16;
+                        const int m = m0 + mloc;
+                        const bool row_ok = m < M;
+                        float v[2][4];
 #pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                    if (nb + e < N) o[e] = v[j][e];
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float x = acc[i][2 * jp + j][e] + bq[j][e];
+                                if (epi == 1) x = gelu_erfc(x);
+                                // columns past N are the zero padding of the next layer's K; rows past M are written as zeros
+                                v[j][e] = (row_ok && nq + j * 16 + 4 * kq + e < N) ? x : 0.f;
+                            }
+                        if (img) {
+                            u32x2 h0, m0_, l0, h1, m1, l1;
+                            split4(v[0], h0, m0_, l0);
+                            split4(v[1], h1, m1, l1);
+                            pair_swap(h0, h1);
+                            pair_swap(m0_, m1);
+                            pair_swap(l0, l1);
+                            // even rows now hold {own j = 0 half, partner's j = 0 half} in (x0, x1); odd rows {partner's
+                            // j = 1 half, own j = 1 half}: in both cases (first, second) = columns (8 kc .. + 3, + 4 .. + 7)
+                            uint4* o = cl_base + mloc;
+                            store16_sc1(o, u32x4{h0.x, h0.y, h1.x, h1.y});
+                            store16_sc1(o + 4 * 128, u32x4{m0_.x, m0_.y, m1.x, m1.y});
+                            store16_sc1(o + 8 * 128, u32x4{l0.x, l0.y, l1.x, l1.y});
+                        }
+                        if (C && row_ok) {
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const int nb = nq + j * 16 + 4 * kq;
+                                float* o = C + (size_t)m * ldc + nb;
+                                if (vec && nb + 3 < N) {
+                                    // write-through as well: nothing of this launch is left dirty in the L2s when it ends
+                                    store16_sc1(reinterpret_cast<uint4*>(o), __builtin_bit_cast(u32x4, f32x4{v[j][0], v[j][1], v[j][2], v[j][3]}));
+                                } else {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        if (nb + e < N) o[e] = v[j][e];
+                                }
                             }
                         }
                     }
@@ -497,6 +506,7 @@ __global__ __launch_bounds__(256) void mlp_chain(const ChainArgs P) {
                 cq = nq_; cidx = nidx_;
                 l = nl_; rb = nrb_; tn = ntn_;
                 a_cur = a_n; w_cur = w_n;
+                kind = tile_kind(l, tn);
                 continue;
             } else {
                 // slow path: end of a queue, a dependency that was not ready at the poll, or a tile of < 4 slabs
@@ -530,7 +540,8 @@ __global__ __launch_bounds__(256) void mlp_chain(const ChainArgs P) {
                 l = __builtin_amdgcn_readfirstlane(l); rb = __builtin_amdgcn_readfirstlane(rb);
                 tn = __builtin_amdgcn_readfirstlane(tn);
                 a_cur = a_src(l, rb); w_cur = w_src(l, tn);
-                HD_STAGE(a_cur, w_cur, 0)
+                kind = tile_kind(l, tn);
+                HD_STAGE(a_cur, w_cur, 0, kind)
                 continue;
             }
         }
@@ -590,6 +601,26 @@ extern "C" int hd_mlp_chain_limbs_f32(const void* A0, int64_t rows, const hd_mlp
     P.n_layers = n_layers;
     P.M = (int)rows;
     P.tiles_m = (int)((rows + 127) / 128);
+    struct Knobs { int n_cu, delay_ns, flags, reload, per_cu; };
+    static Knobs knobs = [] {
+        Knobs k{256, 0, 0, 0, 2};
+        if (const char* e = getenv("HD_MLP_CHAIN_PER_CU")) k.per_cu = atoi(e);
+        if (const char* e = getenv("HD_MLP_CHAIN_DELAY_NS")) k.delay_ns = atoi(e);
+        if (const char* e = getenv("HD_MLP_CHAIN_FLAGS")) k.flags = atoi(e);
+        if (const char* e = getenv("HD_GEMM_TUNE_RELOAD")) k.reload = atoi(e);
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            k.n_cu = prop.multiProcessorCount;
+        return k;
+    }();
+    if (knobs.reload) {
+        if (const char* e = getenv("HD_MLP_CHAIN_DELAY_NS")) knobs.delay_ns = atoi(e);
+        if (const char* e = getenv("HD_MLP_CHAIN_FLAGS")) knobs.flags = atoi(e);
+        if (const char* e = getenv("HD_MLP_CHAIN_PER_CU")) knobs.per_cu = atoi(e);
+    }
+    const int per_cu = knobs.per_cu >= 1 && knobs.per_cu <= 2 ? knobs.per_cu : 2;
+    const int64_t grid_full = (int64_t)knobs.n_cu * per_cu / 8 * 8 > 8 ? (int64_t)knobs.n_cu * per_cu / 8 * 8 : 8;
     int64_t items = 0;
     for (int i = 0; i < n_layers; ++i) {
         const hd_mlp_chain_layer& s = layers[i];
@@ -611,7 +642,13 @@ extern "C" int hd_mlp_chain_limbs_f32(const void* A0, int64_t rows, const hd_mlp
         L.out_f32 = (float*)s.out_f32;
         L.N = (int)s.N;
         L.nslab = (int)((s.K + 31) / 32);
-        L.tiles_n = (int)((s.N + BNT - 1) / BNT);
+        // Every layer wide by default.  Narrow (64-wide) tiles for the whole LAST layer when its wide tiles are fewer than
+        // two per workgroup (flag 16: the launch ends on that layer, and tiles of half the length leave the workgroups
+        // idle for half as long at the end) measured 467 against 460 us, inside the noise, so it is not the default;
+        // flag 32 = every layer narrow (the 128 x 64 tiling of csrc/gemm_limbs.hip): 521 us on the same box.
+        const int64_t wide_tiles = (s.N + BNT - 1) / BNT * P.tiles_m;
+        L.wide = (knobs.flags & 32) ? 0 : !((knobs.flags & 16) && last && n_layers > 1 && wide_tiles < 2 * grid_full);
+        L.tiles_n = (int)(L.wide ? (s.N + BNT - 1) / BNT : (s.N + 63) / 64);
         L.nslab_out = (int)((s.N + 31) / 32);
         L.epi = s.epi;
         L.ldc = (int)(s.out_f32 ? s.ldc : s.N);
@@ -620,39 +657,18 @@ extern "C" int hd_mlp_chain_limbs_f32(const void* A0, int64_t rows, const hd_mlp
     }
     P.cum[n_layers] = (int)items;
     HD_REQUIRE(items * ((P.tiles_m + 7) / 8) < (1LL << 30), "hd_mlp_chain_limbs_f32: too many tiles");
-    struct Knobs { int n_cu, delay_ns, flags, reload, per_cu; };
-    static Knobs knobs = [] {
-        Knobs k{256, 0, 0, 0, 2};
-        if (const char* e = getenv("HD_MLP_CHAIN_PER_CU")) k.per_cu = atoi(e);
-        if (const char* e = getenv("HD_MLP_CHAIN_DELAY_NS")) k.delay_ns = atoi(e);
-        if (const char* e = getenv("HD_MLP_CHAIN_FLAGS")) k.flags = atoi(e);
-        if (const char* e = getenv("HD_GEMM_TUNE_RELOAD")) k.reload = atoi(e);
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            k.n_cu = prop.multiProcessorCount;
-        return k;
-    }();
-    if (knobs.reload) {
-        if (const char* e = getenv("HD_MLP_CHAIN_DELAY_NS")) knobs.delay_ns = atoi(e);
-        if (const char* e = getenv("HD_MLP_CHAIN_FLAGS")) knobs.flags = atoi(e);
-        if (const char* e = getenv("HD_MLP_CHAIN_PER_CU")) knobs.per_cu = atoi(e);
-    }
     P.delay_ticks = knobs.delay_ns / 10;
     P.flags = knobs.flags;
     P.dbg = nullptr;
     if (knobs.reload)
         if (const char* e = getenv("HD_MLP_CHAIN_DEBUG_PTR")) P.dbg = (unsigned long long*)strtoull(e, nullptr, 0);
     const int64_t total = items * P.tiles_m;
-    // The kernel's registers (166) and LDS (36 KB) would admit three workgroups per CU; a grid of two per CU is then
-    // NOT spread evenly by the dispatcher (some CUs get three, others one).  Unused dynamic LDS pads the footprint so
-    // that exactly `per_cu` workgroups fit a CU (160 KB) and the grid fills the chip evenly.
-    const int per_cu = knobs.per_cu >= 1 && knobs.per_cu <= 3 ? knobs.per_cu : 2;
-    int64_t grid = (int64_t)knobs.n_cu * per_cu / 8 * 8;
-    if (grid < 8) grid = 8;
+    // The kernel's registers (252) admit two workgroups per CU, its LDS (48 KB) three; unused dynamic LDS pads the
+    // footprint so that exactly `per_cu` workgroups fit a CU (160 KB) and the grid fills the chip evenly.
+    int64_t grid = grid_full;
     if (grid > total) grid = total;
     const size_t static_lds = CH_BUF * 16 + 64;
-    const size_t want = per_cu == 3 ? 0 : (per_cu == 2 ? 56 * 1024 : 100 * 1024);
+    const size_t want = per_cu == 2 ? 56 * 1024 : 100 * 1024;
     const size_t pad = want > static_lds ? want - static_lds : 0;
     static bool attr_set[64] = {};                  // per device: the attribute belongs to the device's code object
     int dev = 0;
