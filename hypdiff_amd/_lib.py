@@ -26,7 +26,7 @@ class HdChainLayer(ctypes.Structure):
 class HdMlpChainLayer(ctypes.Structure):
     """struct hd_mlp_chain_layer of include/hypdiff.h"""
     _fields_ = [("W", c_void_p), ("bias", c_void_p), ("out_image", c_void_p), ("out_f32", c_void_p), ("N", c_int64),
-                ("K", c_int64), ("ldc", c_int64), ("epi", c_int32)]
+                ("K", c_int64), ("ldc", c_int64), ("epi", c_int32), ("z_out", c_void_p), ("aux", c_void_p)]
 
 
 class HdPackJob(ctypes.Structure):

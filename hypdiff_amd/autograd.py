@@ -236,12 +236,23 @@ class LinearStack(torch.autograd.Function):
             a, wimgs = imgs[0], imgs[1:1 + L]
             ctx.wt_imgs = [None] + imgs[1 + L:] if train else None
             h = None
-            for l, kind in enumerate(kinds):
-                last = l == L - 1
-                a_imgs.append(a)
-                z, h, a = gemm_limbs_train(a, wimgs[l], bs_[l].detach(), None, 1 if kind == GELU else 0,
-                                           want_z=kind == GELU and train, want_f32=last, want_limbs=not last)
-                zs.append(z)
+            ctx.chain = ops.mlp_chain_train_ok(a, L)
+            if ctx.chain:
+                # all layers in ONE persistent launch (csrc/gemm_chain.hip): same tiles' arithmetic as the per-layer
+                # launches, bit-identical outputs
+                outs = ops._mlp_chain_launch(a, [
+                    {"w": wimgs[l], "bias": bs_[l].detach(), "epi": 1 if kind == GELU else 0, "img": l < L - 1,
+                     "f32": l == L - 1, "z": kind == GELU and train} for l, kind in enumerate(kinds)])
+                a_imgs = [a] + [o[0] for o in outs[:-1]]
+                zs = [o[2] for o in outs]
+                h = outs[-1][1]
+            else:
+                for l, kind in enumerate(kinds):
+                    last = l == L - 1
+                    a_imgs.append(a)
+                    z, h, a = gemm_limbs_train(a, wimgs[l], bs_[l].detach(), None, 1 if kind == GELU else 0,
+                                               want_z=kind == GELU and train, want_f32=last, want_limbs=not last)
+                    zs.append(z)
             ctx.x_imgs = a_imgs if train else None
             ctx.kinds = kinds
             ctx.params = params
@@ -343,7 +354,18 @@ class LinearStack(torch.autograd.Function):
         grads = [None] * (2 * L)
         dz_img = ops.limb_pack(gy.contiguous(), "bf16x3")
         sink = GRAD_SINK
+        dz_imgs = None
+        if ctx.chain and L >= 3:
+            # the input-gradient GEMMs dz_{l-1} = (dz_l W_l) gelu'(z_{l-1}), l = L-1 .. 1, are row-parallel like the
+            # forward pass: one persistent launch; the weight-gradient GEMMs then read the dz images it left
+            outs = ops._mlp_chain_launch(dz_img, [{"w": ctx.wt_imgs[l], "epi": 3, "img": True, "aux": zs[l - 1]}
+                                                  for l in range(L - 1, 0, -1)])
+            dz_imgs = {L - 1: dz_img}
+            for k, l in enumerate(range(L - 1, 0, -1)):
+                dz_imgs[l - 1] = outs[k][0]
         for l in range(L - 1, -1, -1):
+            if dz_imgs is not None:
+                dz_img = dz_imgs[l]
             shp = ctx.wshapes[l]
             wp, bp = ctx.params[2 * l], ctx.params[2 * l + 1]
             wv = sink.view_for(wp) if sink is not None else None
@@ -358,7 +380,8 @@ class LinearStack(torch.autograd.Function):
                 grads[2 * l + 1] = db if db.numel() == shp[0] else db[: shp[0]].contiguous()
             if l == 0:
                 break
-            _, _, dz_img = gemm_limbs_train(dz_img, ctx.wt_imgs[l], None, zs[l - 1], 3, want_f32=False, want_limbs=True)
+            if dz_imgs is None:
+                _, _, dz_img = gemm_limbs_train(dz_img, ctx.wt_imgs[l], None, zs[l - 1], 3, want_f32=False, want_limbs=True)
         ctx.x_imgs = ctx.wt_imgs = None
         return (None, None, *grads)
 

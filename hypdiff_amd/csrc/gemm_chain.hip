@@ -72,6 +72,8 @@ struct Layer {
     const float* bias;       // N floats or null
     uint4* out_img;          // limb image of the output (M, N), or null
     float* out_f32;          // fp32 output (M, N) with row pitch ldc, or null
+    float* z_out;            // fp32 pre-activation (M, N) with row pitch ldc, or null (training forward)
+    const float* aux;        // epi 3: fp32 z of the layer below (M, N) with row pitch ldc
     int N, nslab, tiles_n, nslab_out, epi, ldc;
     int wide;                // 1: column tiles of 128 (the last one narrow when <= 64 columns are left); 0: all tiles 64 wide
 };
@@ -430,7 +432,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                 const float* __restrict__ bias = Ly.bias;
                 uint4* __restrict__ CL = Ly.out_img;
                 float* __restrict__ C = Ly.out_f32;
-                const bool vec = (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+                float* __restrict__ Z = Ly.z_out;
+                const float* __restrict__ AUX = Ly.aux;
+                // (the host checks that every fp32 pointer is 16-byte aligned)
+                const bool vec = (ldc & 3) == 0;
                 // this lane's chunk after the pair swap: even 16-lane rows keep the even accumulator of a pair (chunk
                 // kc = kq / 2), odd rows the odd one (kc = 2 + kq / 2)
                 const int kc_mine = (kq & 1) * 2 + (kq >> 1);
@@ -457,14 +462,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                         const bool row_ok = m < M;
                         float v[2][4];
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
+                        for (int j = 0; j < 2; ++j) {
+                            const int nb = nq + j * 16 + 4 * kq;
+                            float x[4];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                float x = acc[i][2 * jp + j][e] + bq[j][e];
-                                if (epi == 1) x = gelu_erfc(x);
-                                // columns past N are the zero padding of the next layer's K; rows past M are written as zeros
-                                v[j][e] = (row_ok && nq + j * 16 + 4 * kq + e < N) ? x : 0.f;
+                            for (int e = 0; e < 4; ++e) x[e] = acc[i][2 * jp + j][e] + bq[j][e];
+                            if (Z && row_ok) {                  // training: the pre-activation is kept for the backward pass
+                                float* zo = Z + (size_t)m * ldc + nb;
+                                if (vec && nb + 3 < N) {
+                                    __builtin_nontemporal_store(f32x4{x[0], x[1], x[2], x[3]}, reinterpret_cast<f32x4*>(zo));
+                                } else {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        if (nb + e < N) zo[e] = x[e];
+                                }
                             }
+                            if (epi == 3) {                     // backward: dz_below = g * gelu'(z_below)
+                                float r[4] = {0.f, 0.f, 0.f, 0.f};
+                                if (row_ok) {
+                                    const float* rp = AUX + (size_t)m * ldc + nb;
+                                    if (vec && nb + 3 < N) {
+                                        const float4 q = *reinterpret_cast<const float4*>(rp);
+                                        r[0] = q.x; r[1] = q.y; r[2] = q.z; r[3] = q.w;
+                                    } else {
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e)
+                                            if (nb + e < N) r[e] = rp[e];
+                                    }
+                                }
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) x[e] *= gelu_erf_grad(r[e]);
+                            } else if (epi == 1) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) x[e] = gelu_erfc(x[e]);
+                            }
+                            // columns past N are the zero padding of the next layer's K; rows past M are written as zeros
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[j][e] = (row_ok && nb + e < N) ? x[e] : 0.f;
+                        }
                         if (img) {
                             u32x2 h0, m0_, l0, h1, m1, l1;
                             split4(v[0], h0, m0_, l0);
@@ -576,6 +611,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
             if (Lz.out_f32)
                 for (size_t i = tid; i < (size_t)M * Lz.ldc; i += 256)
                     if ((int)(i % Lz.ldc) < Lz.N) Lz.out_f32[i] = __builtin_nanf("");
+            if (Lz.out_img) {                                   // every limb a bf16 NaN
+                const size_t chunks = (size_t)tiles_m * Lz.nslab_out * kTile;
+                for (size_t i = tid; i < chunks; i += 256) Lz.out_img[i] = make_uint4(0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u);
+            }
         }
     }
 }
@@ -628,18 +667,24 @@ extern "C" int hd_mlp_chain_limbs_f32(const void* A0, int64_t rows, const hd_mlp
         HD_REQUIRE(i == 0 || s.K == layers[i - 1].N, "hd_mlp_chain_limbs_f32: layer %d: K = %lld but layer %d has N = %lld", i,
                    (long long)s.K, i - 1, (long long)layers[i - 1].N);
         HD_REQUIRE(s.W && is_aligned16(s.W), "hd_mlp_chain_limbs_f32: layer %d: null or misaligned weight image", i);
-        HD_REQUIRE(s.epi == 0 || s.epi == 1, "hd_mlp_chain_limbs_f32: layer %d: epilogue must be 0 (none) or 1 (GELU)", i);
+        HD_REQUIRE(s.epi == 0 || s.epi == 1 || s.epi == 3, "hd_mlp_chain_limbs_f32: layer %d: epilogue must be 0 (none), 1 (GELU) or 3 (backward)", i);
+        HD_REQUIRE(s.epi != 3 || (s.aux && !s.bias), "hd_mlp_chain_limbs_f32: layer %d: epilogue 3 needs aux and no bias", i);
+        HD_REQUIRE(is_aligned16(s.out_f32) && is_aligned16(s.z_out) && is_aligned16(s.aux),
+                   "hd_mlp_chain_limbs_f32: layer %d: fp32 pointers must be 16-byte aligned", i);
         const bool last = i == n_layers - 1;
         HD_REQUIRE(last || (s.out_image && is_aligned16(s.out_image)),
                    "hd_mlp_chain_limbs_f32: layer %d: an inner layer needs a (16-byte aligned) output image", i);
         HD_REQUIRE(!last || s.out_f32 || s.out_image, "hd_mlp_chain_limbs_f32: the last layer needs an output");
-        HD_REQUIRE(!s.out_f32 || s.ldc >= s.N, "hd_mlp_chain_limbs_f32: layer %d: leading dimension too small", i);
-        HD_REQUIRE((int64_t)rows * (s.out_f32 ? s.ldc : 1) < (1LL << 40), "hd_mlp_chain_limbs_f32: output too large");
+        const bool f32io = s.out_f32 || s.z_out || s.epi == 3;
+        HD_REQUIRE(!f32io || s.ldc >= s.N, "hd_mlp_chain_limbs_f32: layer %d: leading dimension too small", i);
+        HD_REQUIRE((int64_t)rows * (f32io ? s.ldc : 1) < (1LL << 40), "hd_mlp_chain_limbs_f32: output too large");
         Layer& L = P.L[i];
         L.W = (const uint4*)s.W;
         L.bias = (const float*)s.bias;
         L.out_img = (uint4*)s.out_image;
         L.out_f32 = (float*)s.out_f32;
+        L.z_out = (float*)s.z_out;
+        L.aux = s.epi == 3 ? (const float*)s.aux : nullptr;
         L.N = (int)s.N;
         L.nslab = (int)((s.K + 31) / 32);
         // Every layer wide by default.  Narrow (64-wide) tiles for the whole LAST layer when its wide tiles are fewer than
@@ -651,7 +696,7 @@ extern "C" int hd_mlp_chain_limbs_f32(const void* A0, int64_t rows, const hd_mlp
         L.tiles_n = (int)(L.wide ? (s.N + BNT - 1) / BNT : (s.N + 63) / 64);
         L.nslab_out = (int)((s.N + 31) / 32);
         L.epi = s.epi;
-        L.ldc = (int)(s.out_f32 ? s.ldc : s.N);
+        L.ldc = (int)(f32io ? s.ldc : s.N);
         P.cum[i] = (int)items;
         items += L.tiles_n;
     }

@@ -538,47 +538,76 @@ def mlp_chain_ok(a, layers):
             and all(w.dtype == torch.float32 for w, _, _ in layers))
 
 
-def mlp_chain(a, layers, out=None):
-    """layers = [(weight, bias, epi), ...] over the limb image `a`: every layer's tiles in one launch, a row block
-    flows from layer to layer as soon as its own tiles are complete.  Bit-identical to the per-layer launches."""
+def _mlp_chain_launch(a, specs):
+    """One hd_mlp_chain_limbs_f32 launch.  specs: one dict per layer with w (LimbImage of the weight), bias, epi and the
+    outputs wanted: img (limb image), f32 (fp32 tensor, or a tensor to write into), z (fp32 pre-activation), aux (epi 3:
+    z of the layer below).  fp32 rows are padded to 64 bytes as gemm_limbs_train's are.  Returns [(img, f32, z), ...]."""
     dev = a.buf.device
     M = a.rows
-    arr = (_lib.HdMlpChainLayer * len(layers))()
-    keep, k_in, flops, nbytes = [], a.cols, 0.0, 0.0
-    for i, (w, b, epi) in enumerate(layers):
-        last = i == len(layers) - 1
-        wl, _ = weight_limbs(w, "bf16x3")
+    arr = (_lib.HdMlpChainLayer * len(specs))()
+    keep, outs, k_in, flops, nbytes = [], [], a.cols, 0.0, 0.0
+    for i, sp in enumerate(specs):
+        wl, bd, epi = sp["w"], sp.get("bias"), sp["epi"]
         assert wl.cols == k_in, (wl.cols, k_in)
-        bd = None if b is None else b.detach()
         n = wl.rows
-        img = None if last else limb_empty(M, n, dev, "bf16x3")
-        c = None
-        if last:
-            c = out if out is not None else torch.empty(M, n, dtype=torch.float32, device=dev)
-        keep += [wl, bd, img, c]
-        arr[i] = _lib.HdMlpChainLayer(_p(wl.buf), _p(bd), _p(img.buf) if img is not None else None, _p(c), n, k_in,
-                                      c.stride(0) if c is not None else n, epi)
+        ld = (n + 15) // 16 * 16
+        img = limb_empty(M, n, dev, "bf16x3") if sp.get("img") else None
+        c = sp.get("f32")
+        if c is False:
+            c = None
+        elif c is True:
+            c = torch.empty(M, ld, dtype=torch.float32, device=dev)[:, :n]
+        z = torch.empty(M, ld, dtype=torch.float32, device=dev)[:, :n] if sp.get("z") else None
+        aux = sp.get("aux")
+        pitches = {t.stride(0) for t in (c, z, aux) if t is not None}
+        assert len(pitches) <= 1, pitches
+        ldc = pitches.pop() if pitches else n
+        keep += [wl, bd, img, c, z, aux]
+        outs.append((img, c, z))
+        arr[i] = _lib.HdMlpChainLayer(_p(wl.buf), _p(bd), _p(img.buf) if img is not None else None, _p(c), n, k_in, ldc,
+                                      epi, _p(z), _p(aux))
         kp, npad = (k_in + 31) // 32 * 32, (n + 31) // 32 * 32
         flops += 2.0 * M * n * k_in
-        nbytes += 6.0 * (M * kp + n * kp) + (4.0 * M * n if last else 6.0 * M * npad)
+        nbytes += (6.0 * (M * kp + n * kp) + 4.0 * M * n * ((c is not None) + (z is not None) + (aux is not None))
+                   + (6.0 * M * npad if img is not None else 0.0))
         k_in = n
-    key = (dev.index, torch.cuda.current_stream().cuda_stream, (M + 127) // 128, len(layers))
+    key = (dev.index, torch.cuda.current_stream().cuda_stream, (M + 127) // 128, len(specs))
     ws = _mlp_chain_ws.get(key)
     if ws is None:
         # zero-filled once: the kernel leaves it clean for the next launch on this stream
         if len(_mlp_chain_ws) > 64:
             _mlp_chain_ws.clear()
-        ws = _mlp_chain_ws[key] = torch.zeros(_lib.load().hd_mlp_chain_workspace_bytes(M, len(layers)) // 4 + 4,
+        ws = _mlp_chain_ws[key] = torch.zeros(_lib.load().hd_mlp_chain_workspace_bytes(M, len(specs)) // 4 + 4,
                                               dtype=torch.int32, device=dev)
     ev = GEMM_EVENTS
     if ev is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.call("hd_mlp_chain_limbs_f32", _p(a.buf), M, arr, len(layers), _p(ws), ws.numel() * 4, _stream())
+    _lib.call("hd_mlp_chain_limbs_f32", _p(a.buf), M, arr, len(specs), _p(ws), ws.numel() * 4, _stream())
     if ev is not None:
         e1.record()
         ev.append((e0, e1, flops, nbytes, "mlp_chain"))
-    return keep[-1]
+    return outs
+
+
+def mlp_chain(a, layers, out=None):
+    """layers = [(weight, bias, epi), ...] over the limb image `a`: every layer's tiles in one launch, a row block
+    flows from layer to layer as soon as its own tiles are complete.  Bit-identical to the per-layer launches."""
+    specs = []
+    for i, (w, b, epi) in enumerate(layers):
+        last = i == len(layers) - 1
+        wl, _ = weight_limbs(w, "bf16x3")
+        c = None
+        if last:
+            c = out if out is not None else torch.empty(a.rows, wl.rows, dtype=torch.float32, device=a.buf.device)
+        specs.append({"w": wl, "bias": None if b is None else b.detach(), "epi": epi, "img": not last, "f32": c})
+    return _mlp_chain_launch(a, specs)[-1][1]
+
+
+def mlp_chain_train_ok(a, n_layers):
+    """the training step's forward / input-gradient stacks can run as one-launch chains"""
+    return (not _NO_MLP_CHAIN and isinstance(a, LimbImage) and a.fmt == "bf16x3" and a.rows >= MLP_CHAIN_MIN_ROWS
+            and 2 <= n_layers <= 8)
 
 
 def mlp_chain_failed():

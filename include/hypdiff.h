@@ -346,7 +346,10 @@ int hd_gemm_limbs_f32(const void* A, const void* W, const void* bias, const void
  * arithmetic and limb images as hd_gemm_limbs_f32, layer by layer (results are bit-identical to n_layers calls of it);
  * the tiles of all layers are one stream of work items pulled by the resident workgroups, a 128-row block flows from
  * layer to layer as soon as its own tiles are complete (csrc/gemm_chain.hip).  A0: limb image of the input (rows, K_0).
- * Layer i: W = limb image of the weight (N, K), bias (N floats or null), epi 0 none / 1 GELU; out_image = limb image
+ * Layer i: W = limb image of the weight (N, K), bias (N floats or null), epi 0 none / 1 GELU / 3 backward
+ * ((A W^T) * gelu'(aux): the input-gradient chain of the training step, dz_{l-1} = (dz_l W_l) gelu'(z_{l-1}), which is
+ * row-parallel like the forward pass; bias must be null), z_out = optional fp32 copy of the pre-activation (what the
+ * backward pass needs of the forward pass), as hd_gemm_limbs_train_f32 writes it; out_image = limb image
  * of the output (required for every layer but the last: hd_limb_image_bytes(rows, N) bytes, written by this call,
  * distinct buffers per layer), out_f32 = fp32 output with row pitch ldc (optional; the last layer needs one of the
  * two).  K of layer i must equal N of layer i - 1; at most 8 layers.  workspace: hd_mlp_chain_workspace_bytes(rows,
@@ -361,6 +364,8 @@ typedef struct hd_mlp_chain_layer {
     void* out_f32;
     int64_t N, K, ldc;
     int32_t epi;
+    void* z_out;        /* training forward: fp32 pre-activation A W^T + bias (rows x N, row pitch ldc), or null */
+    const void* aux;    /* epi 3 only: fp32 z of the layer below (rows x N, row pitch ldc) */
 } hd_mlp_chain_layer;
 int64_t hd_mlp_chain_workspace_bytes(int64_t rows, int n_layers);
 int hd_mlp_chain_limbs_f32(const void* A0, int64_t rows, const hd_mlp_chain_layer* layers, int n_layers, void* workspace,

@@ -91,3 +91,39 @@ def test_chain_no_bias_and_many_launches_stay_clean():
     torch.cuda.synchronize()
     assert all(torch.equal(o, ref) for o in outs)
     assert not ops.mlp_chain_failed()
+
+
+@pytest.mark.parametrize("rows,dims", [
+    (15777, [516, 800, 900, 800, 700, 512]),        # the bench's training leg (cat(x, t) padded to a 16-byte row)
+    (4100, [36, 72, 132, 8]),                       # ragged: the last column tiles narrow, a partial row block
+])
+def test_training_stack_through_the_chain_equals_per_layer_launches(rows, dims, monkeypatch):
+    """LinearStack on limb images: forward (with the fp32 pre-activations kept) and the input-gradient GEMMs
+    dz_{l-1} = (dz_l W_l) gelu'(z_{l-1}) as one-launch chains (epilogue 3) must give, bit for bit, the output and every
+    parameter gradient of the per-layer launches (hd_gemm_limbs_train_f32)."""
+    from hypdiff_amd import autograd as ag, ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(rows, dims[0], generator=g).to(dev)
+    gy = torch.randn(rows, dims[-1], generator=g).to(dev)
+    kinds = tuple([ag.GELU] * (len(dims) - 2) + [ag.LIN])
+
+    def run(no_chain):
+        monkeypatch.setattr(ops, "_NO_MLP_CHAIN", no_chain)
+        lin = [torch.nn.Linear(dims[i], dims[i + 1]).to(dev) for i in range(len(dims) - 1)]
+        gg = torch.Generator().manual_seed(5)
+        for m in lin:
+            m.weight.data = (torch.randn(m.weight.shape, generator=gg) / m.weight.shape[1] ** 0.5).to(dev)
+            m.bias.data = torch.randn(m.bias.shape, generator=gg).to(dev)
+        y = ag.linear_stack(x, lin, kinds)
+        y.backward(gy)
+        torch.cuda.synchronize()
+        return y.detach(), [p.grad.clone() for m in lin for p in (m.weight, m.bias)]
+
+    y0, g0 = run(True)
+    y1, g1 = run(False)
+    assert ops._mlp_chain_ws, "the chain did not run"
+    assert torch.equal(y0, y1)
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b), float((a - b).abs().max())
+    assert not ops.mlp_chain_failed()
