@@ -290,7 +290,7 @@ def sharded_leg(device, rank, world, steps, warmup, barrier, dist):
                                  num_layers=2, act="relu", dropout=0.0, bias=0, use_att=0, local_agg=0)
     torch.manual_seed(1432)
     enc = HGCN(torch.tensor([0.6], device=device), args).to(device).eval()
-    csr = hdist.shard_csr(sh, device)
+    csr = hdist.shard_csr(sh, device, halo=sh.use_halo)
     with torch.no_grad():
         for _ in range(warmup):
             hdist.sharded_hgcn_encode(enc, x, sh)
@@ -311,7 +311,11 @@ def sharded_leg(device, rank, world, steps, warmup, barrier, dist):
     return {"metric": "row-sharded HGCN encode nodes/s (config 5 shape)", "value": n * steps / dt, "unit": "nodes/s",
             "steps": steps, "ms_per_step": dt / steps * 1e3, "rows_total": n, "rows_per_gpu": rows_per_rank, "dim": d,
             "nnz_per_gpu": nnz_loc, "hub_rows_per_gpu": int(csr.n_long), "finite": bool(torch.isfinite(h).all()),
+            "exchange": "halo (all_to_all_single of the referenced remote rows)" if sh.use_halo else
+                        "all-gather" + (" (every rank would need >= 50 % of the remote rows)" if world > 1 else ""),
+            "remote_rows_referenced_max_fraction": sh.halo_fraction,
             "allgather_bytes_per_layer_per_gpu": rows_per_rank * d * 4 * (world - 1),
+            "received_bytes_per_layer_per_gpu": sh.halo_bytes(d) if sh.use_halo else rows_per_rank * d * 4 * (world - 1),
             "exposed_collective_ms_per_step": exposed_ms,
             "exposed_note": "HIP events on the compute stream around each slab's wait (rank 0, summed over 2 layers x 4 "
                             "slabs): all-gather time not hidden behind the SpMM of the previous slab; 0 in a world of one",

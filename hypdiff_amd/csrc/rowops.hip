@@ -144,6 +144,55 @@ __global__ __launch_bounds__(256) void hyp_act_rows4(const float* __restrict__ i
     }
 }
 
+// HypAct for fp32 rows of at most 64 columns: 16 lanes per row, 32 rows per wavefront and pass (tile k of a lane's
+// 16-lane group g is row base + 4 k + g, so each of the eight loads of a wavefront is 4 consecutive rows).  The scalar
+// chain runs once per pass with row (k, g) in lane 16 g + k (lanes 8..15 of a group repeat rows 0..7), and its results
+// go back to the row's 16 lanes with one DPP row broadcast each (the generic row kernel evaluates the chain in every lane
+// of every row, 16 times over: 0.46-0.49 of the HBM peak at d = 64).
+template <int K> __device__ __forceinline__ float row_bcast(float v) { return dpp_get<0x150 + K>(v); }   // row_newbcast:K
+template <class M>
+__global__ __launch_bounds__(256) void hyp_act_rows32(const float* __restrict__ in, float* __restrict__ out, int64_t n,
+                                                      int d, Curv cin, Curv cout, float slope) {
+    constexpr int R = 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
+    using TL = Tile<float, 16, 4, 4>;
+    for (int64_t base = ((int64_t)blockIdx.x * 4 + wave) * 32; base < n; base += (int64_t)gridDim.x * 4 * 32) {
+        TL r[R];
+        float s1[R], s2[R], x0[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int64_t row = base + 4 * k + g;
+            r[k].init(d);
+            r[k].load(in + (row < n ? row : n - 1) * d);
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            r[k].sumsq_pair(IsHB<M>::value ? 1 : 0, slope, s1[k], s2[k]);
+            x0[k] = IsHB<M>::value ? row_bcast<0>(r[k].v[0]) : 0.f;
+        }
+        float s1_l = s1[0], s2_l = s2[0], x0_l = x0[0];
+#pragma unroll
+        for (int k = 1; k < R; ++k) {
+            const bool mine = (j & 7) == k;
+            s1_l = mine ? s1[k] : s1_l;
+            s2_l = mine ? s2[k] : s2_l;
+            x0_l = mine ? x0[k] : x0_l;
+        }
+        float f_l, t0_l;
+        hyp_act_scalars<float>((M*)nullptr, s1_l, s2_l, x0_l, cin, cout, f_l, t0_l);
+#define HD_ROW(K)                                                                                     \
+        {                                                                                             \
+            const float f = row_bcast<K>(f_l);                                                        \
+            r[K].map([=](float v) { return f * (v > 0.f ? v : (v != v ? v : slope * v)); });          \
+            if (IsHB<M>::value) r[K].set_first(row_bcast<K>(t0_l));                                   \
+            const int64_t row = base + 4 * K + g;                                                     \
+            if (row < n) r[K].store(out + row * d);                                                   \
+        }
+        HD_ROW(0) HD_ROW(1) HD_ROW(2) HD_ROW(3) HD_ROW(4) HD_ROW(5) HD_ROW(6) HD_ROW(7)
+#undef HD_ROW
+    }
+}
+
 #define HD_ACT(fn, M)                                                                                  \
     extern "C" int fn##_f32(const void* in, void* out, int64_t n, int64_t d, hd_curv ci, hd_curv co,  \
                             int act, void* st) {                                                       \
@@ -152,6 +201,15 @@ __global__ __launch_bounds__(256) void hyp_act_rows4(const float* __restrict__ i
             int64_t blocks = (n + 15) / 16;                                                            \
             blocks = blocks < 8192 ? blocks : 8192;                                                    \
             hyp_act_rows4<M<float>><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)st>>>(        \
+                (const float*)in, (float*)out, n, (int)d, mk(ci), mk(co),                              \
+                act == ACT_IDENTITY ? 1.f : (act == ACT_RELU ? 0.f : 0.01f));                          \
+            return check_launch(#fn "_f32");                                                           \
+        }                                                                                              \
+        if (n >= 4096 && d >= 16 && d <= 64 && d % 4 == 0 && in && out && is_aligned16(in) && is_aligned16(out) && \
+            (act == ACT_IDENTITY || act == ACT_RELU || act == ACT_LEAKY_RELU)) {                       \
+            int64_t blocks = (n + 127) / 128;                                                          \
+            blocks = blocks < 4096 ? blocks : 4096;                                                    \
+            hyp_act_rows32<M<float>><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)st>>>(       \
                 (const float*)in, (float*)out, n, (int)d, mk(ci), mk(co),                              \
                 act == ACT_IDENTITY ? 1.f : (act == ACT_RELU ? 0.f : 0.01f));                          \
             return check_launch(#fn "_f32");                                                           \

@@ -346,6 +346,67 @@ class RowShardedAdj:
         # differ by rounding and picks by (rows, long rows); every shard runs the form the whole graph takes
         deg = np.bincount(indices[0].astype(np.int64), minlength=n) if indices.shape[1] else np.zeros(n, np.int64)
         self.n_long_whole = int((deg > 512).sum())
+        self._build_halo(indices)
+
+    HALO_MAX_FRACTION = 0.5
+
+    def _build_halo(self, indices):
+        """Halo exchange lists: which remote rows this rank's block references, per owner, and which
+        of its own rows every peer references.  Every rank is constructed from the global COO, so both come from it
+        without a request round; so does the decision -- halo exchange when EVERY rank references less than half of the
+        rows it does not own (citation graphs), the equal-sized all-gather otherwise (Barabasi-Albert graphs reference
+        ~80 %) -- which all ranks must take alike.  The local block is re-indexed for the halo form: local columns first
+        (col - lo), then the referenced remote rows in (owner, id) order; the ORDER of a row's entries does not change,
+        so its sum is formed exactly as on one GPU."""
+        P, rpr, n = self.world, self.rows_per_rank, self.n
+        self.halo_ids = [np.zeros(0, np.int64) for _ in range(P)]      # global ids this rank needs, per owner
+        self.send_rows = [np.zeros(0, np.int64) for _ in range(P)]     # local rows of this rank that peer r needs
+        self.halo_fraction, self.use_halo = 0.0, False
+        if P == 1:
+            return
+        rows, cols = indices[0].astype(np.int64), indices[1].astype(np.int64)
+        worst = 0.0
+        for r in range(P):
+            lo_r, hi_r = min(n, r * rpr), min(n, (r + 1) * rpr)
+            a, b = np.searchsorted(rows, lo_r, side="left"), np.searchsorted(rows, hi_r, side="left")
+            remote = np.unique(cols[a:b][(cols[a:b] < lo_r) | (cols[a:b] >= hi_r)])
+            worst = max(worst, remote.size / max(1, n - (hi_r - lo_r)))
+            if r == self.rank:
+                owner = remote // rpr
+                self.halo_ids = [remote[owner == q] for q in range(P)]
+            else:
+                mine = remote[(remote >= self.lo) & (remote < self.hi)]
+                self.send_rows[r] = mine - self.lo
+        self.halo_fraction = worst
+        self.use_halo = worst < self.HALO_MAX_FRACTION
+        if self.use_halo:
+            total = sum(h.size for h in self.halo_ids)
+            halo_all = np.concatenate(self.halo_ids) if total else np.zeros(0, np.int64)   # ascending: owners are ranges
+            c = self.local_indices[1]
+            local = (c >= self.lo) & (c < self.hi)
+            newc = np.where(local, c - self.lo, rpr + np.searchsorted(halo_all, c))
+            self.halo_indices = np.vstack((self.local_indices[0], newc)).astype(np.int64)
+            self.halo_shape = (rpr, rpr + total)
+
+    def _halo_exchange(self, x_local, group=None, async_op=False):
+        """(rows_per_rank + halo, width) operand of the re-indexed block: this rank's rows, then the referenced rows of
+        the peers, fetched by ONE all_to_all_single with the precomputed split sizes.  Returns (tensor, work)."""
+        x_local = self._padded(x_local)
+        w = x_local.shape[1]
+        dev = x_local.device
+        if not hasattr(self, "_send_idx") or self._send_idx.device != dev:
+            cat = np.concatenate(self.send_rows) if sum(r.size for r in self.send_rows) else np.zeros(0, np.int64)
+            self._send_idx = torch.from_numpy(cat).to(dev)
+        send = x_local.index_select(0, self._send_idx)
+        buf = torch.empty(self.halo_shape[1], w, dtype=x_local.dtype, device=dev)
+        buf[: self.rows_per_rank].copy_(x_local)
+        work = dist.all_to_all_single(buf[self.rows_per_rank:], send, [int(h.size) for h in self.halo_ids],
+                                      [int(r.size) for r in self.send_rows], group=group, async_op=async_op)
+        return buf, work
+
+    def halo_bytes(self, width, itemsize=4):
+        """bytes this rank receives per exchange of `width` columns (the all-gather receives (P - 1) blocks)"""
+        return sum(int(h.size) for h in self.halo_ids) * width * itemsize
 
     def _padded(self, x_local):
         if x_local.shape[0] == self.rows_per_rank:
@@ -364,6 +425,20 @@ class RowShardedAdj:
         out = torch.empty(self.rows_per_rank * self.world, x_local.shape[1], dtype=x_local.dtype,
                           device=x_local.device)
         dist.all_gather_into_tensor(out, x_local.contiguous(), group=group)
+        return out
+
+    def exchange_slabs(self, x_local, n_slabs, group=None):
+        """gather_slabs in the halo form: per column slab an asynchronous all_to_all_single of the referenced rows
+        only; the tensors are operands of the re-indexed block (shard_csr(..., halo=True))."""
+        x_local = self._padded(x_local)
+        d = x_local.shape[1]
+        n_slabs = max(1, min(n_slabs, d // 4 if d >= 4 else 1))
+        width = (-(-d // n_slabs) + 3) // 4 * 4
+        out = []
+        for lo in range(0, d, width):
+            hi = min(d, lo + width)
+            buf, work = self._halo_exchange(x_local[:, lo:hi], group, async_op=True)
+            out.append((lo, hi, buf, work))
         return out
 
     def gather_slabs(self, x_local, n_slabs, group=None):
@@ -394,6 +469,9 @@ class RowShardedAdj:
         spmm(local_adj, gathered).  `spmm(indices, values, shape, x)` is the device SpMM
         (ops.spmm on a CSR of the local block) -- injected so that the CPU tests can pass a
         host implementation.  Summation order per row is unchanged -> the support rows are bit-identical to 1 GPU."""
+        if self.use_halo:
+            buf, _ = self._halo_exchange(xt_local, group)
+            return spmm(self.halo_indices, self.local_values, self.halo_shape, buf)[: self.hi - self.lo]
         full = self.gather_rows(xt_local, group)
         out = spmm(self.local_indices, self.local_values, self.local_shape, full)
         return out[: self.hi - self.lo]
@@ -403,6 +481,12 @@ class RowShardedAdj:
         column's sum does not involve the other columns, so the result is bit-identical."""
         n_loc = self.hi - self.lo
         outs = []
+        if self.use_halo:
+            for lo, hi, buf, work in self.exchange_slabs(xt_local, n_slabs, group):
+                if work is not None:
+                    work.wait()
+                outs.append(spmm(self.halo_indices, self.local_values, self.halo_shape, buf)[:n_loc])
+            return torch.cat(outs, 1)
         for lo, hi, full, work in self.gather_slabs(xt_local, n_slabs, group):
             if work is not None:
                 work.wait()
@@ -431,28 +515,36 @@ def sharded_hgcn_encode(encoder, x_local, sharded_adj, group=None, n_slabs=4):
     from .models.encoders import _lift
     n_loc = sharded_adj.hi - sharded_adj.lo
     assert x_local.shape[0] == n_loc, (x_local.shape, n_loc)
-    csr = shard_csr(sharded_adj, x_local.device)
+    halo = sharded_adj.use_halo
+    csr = shard_csr(sharded_adj, x_local.device, halo=halo)
     h = _lift(encoder.manifold, x_local, encoder.curvatures[0])
     pipelined = n_slabs > 1 and (sharded_adj.world > 1 or FORCE_COLLECTIVES)
     for layer in encoder.layers:
         xt = layer.linear.forward(h, _tangent=True)
         if pipelined and xt.shape[1] >= 8 and xt.shape[1] % 4 == 0:
-            h = shard_aggregate_slabs(layer, csr, sharded_adj.gather_slabs(xt, n_slabs, group), n_loc)
+            slabs = sharded_adj.exchange_slabs(xt, n_slabs, group) if halo else sharded_adj.gather_slabs(xt, n_slabs, group)
+            h = shard_aggregate_slabs(layer, csr, slabs, n_loc)
+        elif halo:
+            h = shard_aggregate(layer, csr, sharded_adj._halo_exchange(xt, group)[0], n_loc)
         else:
             h = shard_aggregate(layer, csr, sharded_adj.gather_rows(xt, group), n_loc)
     return h
 
 
-def shard_csr(sharded_adj, device):
-    """device CSR of a rank's row block (columns global), built once"""
+def shard_csr(sharded_adj, device, halo=False):
+    """device CSR of a rank's row block, built once: columns global, or (halo) re-indexed to [own rows | referenced
+    remote rows] as RowShardedAdj._build_halo lays them out"""
     from . import ops
-    if not hasattr(sharded_adj, "_csr"):
-        sharded_adj._csr = ops.csr_from_coo(torch.from_numpy(sharded_adj.local_indices).to(device),
-                                            torch.from_numpy(np.ascontiguousarray(sharded_adj.local_values)).to(device),
-                                            sharded_adj.local_shape)
+    attr = "_csr_halo" if halo else "_csr"
+    if not hasattr(sharded_adj, attr):
+        idx = sharded_adj.halo_indices if halo else sharded_adj.local_indices
+        csr = ops.csr_from_coo(torch.from_numpy(idx).to(device),
+                               torch.from_numpy(np.ascontiguousarray(sharded_adj.local_values)).to(device),
+                               sharded_adj.halo_shape if halo else sharded_adj.local_shape)
         assert ops.CSR.LONG_ROW == 512
-        sharded_adj._csr.whole = (sharded_adj.n, sharded_adj.n_long_whole)
-    return sharded_adj._csr
+        csr.whole = (sharded_adj.n, sharded_adj.n_long_whole)
+        setattr(sharded_adj, attr, csr)
+    return getattr(sharded_adj, attr)
 
 
 def shard_aggregate(layer, csr, xt_full, n_loc):

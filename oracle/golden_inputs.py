@@ -44,7 +44,8 @@ def synthetic_graph(kind, n, seed=1432):
 
     kind: 'ba' (preferential attachment, m=4: BA.pkl-like), 'ego' (hub + ring of
     neighbours + chords: SynEgo-like), 'community' (two dense blocks joined by one
-    edge: SynCommunity-like), 'citation' (sparse power-law, m=2)."""
+    edge: SynCommunity-like), 'citation' (sparse power-law, m=2), 'ring' (node i linked to i +- 1, i +- 2 and, one
+    node in twenty, to a random node: a graph whose node order has locality, for the halo form of the row sharding)."""
     rs = np.random.RandomState(seed + n)
     rows, cols = [], []
 
@@ -74,6 +75,12 @@ def synthetic_graph(kind, n, seed=1432):
                 if same and rs.rand() < 0.7:
                     add(i, j)
         add(0, n - 1)
+    elif kind == "ring":
+        for i in range(n):
+            add(i, (i + 1) % n)
+            add(i, (i + 2) % n)
+            if rs.rand() < 0.05:
+                add(i, rs.randint(n))
     else:
         raise ValueError(kind)
     a = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(n, n))

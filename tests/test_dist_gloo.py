@@ -39,9 +39,10 @@ def _worker(rank, world, port, q):
     torch.manual_seed(1)
     for p in lin.parameters():
         torch.nn.init.normal_(p)
-    data = torch.randn(40, 8)
+    nb = 40 if world == 2 else 14 * world          # equal shards: the mean of the shard means is the batch mean
+    data = torch.randn(nb, 8)
     bucket = hdist.GradBucket(lin.parameters())
-    lo, hi = hdist.shard_range(40, rank, world)
+    lo, hi = hdist.shard_range(nb, rank, world)
     lin(data[lo:hi]).pow(2).mean().backward()
     bucket.allreduce_mean_()
     ref = torch.nn.Linear(8, 4)
@@ -62,6 +63,17 @@ def _worker(rank, world, port, q):
     # ... and with the all-gather pipelined in column slabs (asynchronous collectives, one wait per slab)
     out = sh.aggregate_slabs(xt[sh.lo:sh.hi], spmm, n_slabs=3)
     res["agg_slabs"] = torch.equal(out, full[sh.lo:sh.hi])
+    # (3b) the halo form on a graph with locality: only the referenced remote rows travel (all_to_all_single with the
+    #      precomputed lists), the block is re-indexed, the result is the same bits
+    n2 = 611
+    idx2, val2, shape2 = adjacency.process_adj(gi.synthetic_graph("ring", n2))
+    xt2 = torch.from_numpy(np.random.RandomState(6).standard_normal((n2, d)).astype(np.float32))
+    full2 = olayers.spmm_coo(torch.from_numpy(idx2), torch.from_numpy(val2), shape2, xt2)
+    sh2 = hdist.RowShardedAdj(idx2, val2, shape2, rank, world)
+    res["halo_chosen"] = sh2.use_halo and 0 < sh2.halo_fraction < 0.5 and not sh.use_halo
+    res["halo_volume"] = sh2.halo_bytes(d) < 0.2 * (world - 1) * sh2.rows_per_rank * d * 4
+    res["halo_agg"] = torch.equal(sh2.aggregate(xt2[sh2.lo:sh2.hi], spmm), full2[sh2.lo:sh2.hi])
+    res["halo_agg_slabs"] = torch.equal(sh2.aggregate_slabs(xt2[sh2.lo:sh2.hi], spmm, n_slabs=3), full2[sh2.lo:sh2.hi])
     # (4) DataParallelTrainer: 3 Adam steps on equal shards == 3 full-batch Adam steps; ranks start
     #     from different weights (rank 0's are broadcast) and the gradients stay bucket views
     torch.manual_seed(100 + rank)
@@ -70,9 +82,9 @@ def _worker(rank, world, port, q):
     torch.manual_seed(100)
     ref = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.GELU(), torch.nn.Linear(16, 8))
     opt = torch.optim.Adam(ref.parameters(), lr=1e-2)
-    xb, yb = torch.randn(40, 8, generator=torch.Generator().manual_seed(3)), torch.randn(
-        40, 8, generator=torch.Generator().manual_seed(4))
-    lo, hi = hdist.shard_range(40, rank, world)
+    xb, yb = torch.randn(nb, 8, generator=torch.Generator().manual_seed(3)), torch.randn(
+        nb, 8, generator=torch.Generator().manual_seed(4))
+    lo, hi = hdist.shard_range(nb, rank, world)
     for _ in range(3):
         tr.step(lambda: torch.nn.functional.mse_loss(net(xb[lo:hi]), yb[lo:hi]))
         opt.zero_grad()
@@ -96,7 +108,10 @@ def _worker(rank, world, port, q):
         for _ in range(3):
             t2.step(lambda: torch.nn.functional.mse_loss(n2(xb[lo:hi]), yb[lo:hi]))
         outs.append([p_.detach().clone() for p_ in n2.parameters()])
-    res["overlap_equals_blocking"] = all(torch.equal(a, b) for a, b in zip(*outs))
+    # (two ranks: a + b either way, the same bits; with more, a ring all-reduce adds a chunk's elements in an order that
+    # depends on where the chunk starts)
+    same = torch.equal if world == 2 else (lambda a, b: torch.allclose(a, b, rtol=1e-5, atol=1e-7))
+    res["overlap_equals_blocking"] = all(same(a, b) for a, b in zip(*outs))
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
@@ -114,7 +129,23 @@ def test_world2_gloo():
         p.join(60)
         assert p.exitcode == 0
     for rank, res in got:
-        assert all(res.values()), (rank, res)
+        assert all(res.values()), (rank, [k for k, v in res.items() if not v])
+
+
+def test_world3_gloo():
+    """three ranks: the last block is shorter than the others (padding rows), a rank has two peers to exchange with"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(3)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, res in got:
+        assert all(res.values()), (rank, [k for k, v in res.items() if not v])
 
 
 def test_shard_range_covers():

@@ -113,6 +113,33 @@ def test_manifold_vs_oracle_sizes(mname, d):
                                      what="sqdist", exact=getattr(om, pre + "sqdist")(p.double(), q.double(), c))
 
 
+@pytest.mark.parametrize("mname", ["PoincareBall", "Hyperboloid"])
+@pytest.mark.parametrize("d", [16, 48, 64])
+def test_hyp_act_narrow_rows_32_per_wavefront(mname, d):
+    """hyp_act_rows32 (csrc/rowops.hip: rows of <= 64 columns, >= 4096 of them, 32 rows per wavefront and pass, the
+    scalar chain once per row): against the oracle (layers/hyp_layers.py:170-173) on a row count off every boundary, and
+    for the other activations against the generic row kernel (which short inputs still take)."""
+    import hypdiff_amd.manifolds as hm
+    from hypdiff_amd import ops
+    man = getattr(hm, mname)()
+    pre = "pb_" if mname == "PoincareBall" else "hb_"
+    rs = np.random.RandomState(d)
+    n = 4099
+    u = (rs.standard_normal((n, d)) * rs.choice([0.05, 2.0], size=(n, 1)) / np.sqrt(d)).astype(np.float32)
+    u[0] = 0
+    u[n - 1] = 0
+    for c in (0.6, 1.0):
+        with torch.no_grad():
+            p = getattr(om, pre + "proj")(getattr(om, pre + "expmap0")(torch.from_numpy(u), c), c)
+        pg = p.cuda()
+        got = ops.hyp_act(man.abi, pg, c, 1.0, 1)
+        assert_close(H(got), olayers.hyp_act(mname, p, c, 1.0), what="hyp_act rows32")
+        for act in (0, 1, 5, 2):                       # identity, relu, leaky_relu on the new kernel; tanh on the generic one
+            full = ops.hyp_act(man.abi, pg, c, 0.8, act)
+            parts = torch.cat([ops.hyp_act(man.abi, pg[i:i + 1000].contiguous(), c, 0.8, act) for i in range(0, n, 1000)])
+            assert_close(H(full), H(parts), what="hyp_act rows32 vs row kernel, act %d" % act)
+
+
 def test_empty_inputs():
     import hypdiff_amd.manifolds as hm
     for man in (hm.PoincareBall(), hm.Hyperboloid()):
@@ -819,4 +846,46 @@ def test_row_sharded_encode_equals_full(mname, c):
                 gathered = torch.cat([torch.cat([xt, xt.new_zeros(s.rows_per_rank - xt.shape[0], xt.shape[1])])
                                       for s, xt in zip(shards, xts)])
                 hs = [hdist.shard_aggregate(layer, hdist.shard_csr(s, "cuda"), gathered, s.hi - s.lo) for s in shards]
+            assert torch.equal(torch.cat(hs), full), world
+
+
+@pytest.mark.parametrize("mname,c", [("PoincareBall", 0.6), ("Hyperboloid", 1.0)])
+def test_row_sharded_encode_halo_form_equals_full(mname, c):
+    """The halo form of the row-sharded encode (dist.RowShardedAdj._build_halo: the block re-indexed to [own rows |
+    referenced remote rows], only those rows exchanged) on a graph with locality (a ring with short chords, < 50 % of the
+    remote rows referenced): world = 2 and 3 simulated in-process -- the exchange is an index_select of the rows the
+    lists name; the all_to_all_single itself is covered by the gloo test.  A row's entries keep their order, so the
+    result is bit-identical to the 1-GPU encode."""
+    import types
+    from hypdiff_amd import dist as hdist
+    from hypdiff_amd.models.encoders import HGCN, _lift
+    n, feat, dim = 4500, 12, 32
+    idx, val, shape = adjacency.process_adj(gi.synthetic_graph("ring", n))
+    rs = np.random.RandomState(5)
+    x = rs.standard_normal((n, feat)).astype(np.float32) * 0.3
+    if mname == "Hyperboloid":
+        x = np.concatenate([np.zeros((n, 1), np.float32), x], 1)
+    args = types.SimpleNamespace(manifold=mname, c=c, cuda=0, device="cuda:0", feat_dim=x.shape[1], dim=dim,
+                                 num_layers=2, act="relu", dropout=0.0, bias=0, use_att=0, local_agg=0)
+    torch.manual_seed(3)
+    enc = HGCN(torch.tensor([c]).cuda(), args).cuda().eval()
+    adj = torch.sparse_coo_tensor(G(idx), G(val), shape, check_invariants=False)
+    with torch.no_grad():
+        full = enc.encode(G(x), adj)
+        for world in (2, 3):
+            shards = [hdist.RowShardedAdj(idx, val, shape, r, world) for r in range(world)]
+            assert all(s.use_halo and 0 < s.halo_fraction < 0.5 for s in shards)
+            # what rank r sends to rank q is what rank q expects from rank r
+            for q, sq in enumerate(shards):
+                for r, sr in enumerate(shards):
+                    assert np.array_equal(sr.send_rows[q] + sr.lo, sq.halo_ids[r])
+            hs = [_lift(enc.manifold, G(x[s.lo:s.hi]), enc.curvatures[0]) for s in shards]
+            for layer in enc.layers:
+                xts = [layer.linear.forward(h, _tangent=True) for h in hs]
+                gathered = torch.cat([torch.cat([xt, xt.new_zeros(s.rows_per_rank - xt.shape[0], xt.shape[1])])
+                                      for s, xt in zip(shards, xts)])
+                bufs = [torch.cat([gathered[s.rank * s.rows_per_rank:(s.rank + 1) * s.rows_per_rank],
+                                   gathered[torch.from_numpy(np.concatenate(s.halo_ids)).cuda()]]) for s in shards]
+                hs = [hdist.shard_aggregate(layer, hdist.shard_csr(s, "cuda", halo=True), b, s.hi - s.lo)
+                      for s, b in zip(shards, bufs)]
             assert torch.equal(torch.cat(hs), full), world
