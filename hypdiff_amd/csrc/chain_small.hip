@@ -26,8 +26,8 @@
 // only after it has read all of layer l's input, which exists only once every member has finished reading layer
 // l - 1's input -- the buffer being overwritten.  Tags never repeat inside the workspace: the epoch (1..2046) lives
 // in the workspace header, the last workgroup to leave a launch advances it and, when it wraps, zeroes the words
-// (tag 0 is never waited for; the caller zero-fills a new workspace once).  The launch is cooperative (every
-// workgroup resident: a spinning consumer cannot starve a producer that has not started), and every wait is
+// (tag 0 is never waited for; the caller zero-fills a new workspace once).  The grid fits the chip at once (checked at
+// the launch; see there why it is an ordinary launch and not a cooperative one by default), and every wait is
 // bounded by a 2 s wall clock, after which the workgroup raises the fail flag and the outputs are NaN.
 #include "hd_common.cuh"
 #include "hd_gelu.cuh"
@@ -388,6 +388,31 @@ extern "C" int hd_linear_chain_small_f32(const void* x, int64_t ldx, int64_t row
     const char* wh = getenv("HD_CHAIN_TEST_WITHHOLD");                  // tests: force the time-out path (see the kernel)
     int withhold = wh && wh[0] == '1';
     void* args[] = {&xp, &ldx, &rows_i, &ch, &ep, &emb_idx, &emb_rows_i, &op, &ldo, &hdr, &buf0, &buf1, &RT, &withhold};
+    // An ordinary launch on the caller's stream by default; HD_CHAIN_SMALL_LAUNCH=coop asks for the cooperative one.  The
+    // cooperative launch goes through a queue of its own: two cross-queue hand-overs per call (10 + 28 us around a 175 us
+    // kernel), and when that queue is the process's fifth or later (GPU_MAX_HW_QUEUES = 4) the hardware queues are
+    // oversubscribed and every hand-over costs ~45 us: the sampler step measured 0.33 instead of 0.20 ms whenever the first
+    // cooperative launch came after other streams had been created (profiles/r03_coop_order_trace.txt); the ordinary launch
+    // measures 0.18 ms in either order.  Residency: the grid must fit the chip at once (checked here with the occupancy
+    // query, else the cooperative launch is used); 256 workgroups of one wavefront per SIMD fit an idle MI355X twice over.
+    // Beside other kernels a workgroup may start late -- the others wait for its data, other kernels finish, it starts --
+    // and two launches of this kernel at once on one GPU remain forbidden (hypdiff.h); every wait is bounded, so a starved
+    // launch ends in NaN outputs + hd_chain_failed, never in a hang.
+    static const bool plain = [] {
+        const char* v = getenv("HD_CHAIN_SMALL_LAUNCH");
+        if (v && v[0] == 'c') return false;
+        int dev = 0, per_cu = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(linear_chain_small), 256, 0) != hipSuccess)
+            return false;
+        return (long)per_cu * prop.multiProcessorCount >= (long)kGroups * kG;
+    }();
+    if (plain) {
+        linear_chain_small<<<dim3(kGroups * kG), dim3(256), 0, (hipStream_t)st>>>(xp, ldx, rows_i, ch, ep, emb_idx, emb_rows_i, op,
+                                                                                  ldo, hdr, buf0, buf1, RT, withhold);
+        return check_launch("hd_linear_chain_small_f32");
+    }
     e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(linear_chain_small), dim3(kGroups * kG), dim3(256), args,
                                    0, (hipStream_t)st);
     if (e != hipSuccess) {

@@ -667,7 +667,7 @@ def chain_small_ok(x, layers):
 
 def linear_chain_small(x, layers, emb_after=None, emb=None, emb_idx=None):
     """layers = [(weight, bias, epi), ...] as linear_chain; after layer `emb_after` the rows of `emb` selected by
-    `emb_idx` (int64) are added (ddpm.py:39).  One cooperative launch; the workspace is kept per device and stream."""
+    `emb_idx` (int64) are added (ddpm.py:39).  One launch of 256 co-resident workgroups; the workspace is kept per device and stream."""
     _dev(x)
     x = x if x.stride(1) == 1 else x.contiguous()
     n = x.shape[0]

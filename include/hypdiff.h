@@ -304,15 +304,17 @@ typedef struct hd_pack_job {
 } hd_pack_job;
 int hd_limb_pack_multi_f32(const hd_pack_job* jobs, int n_jobs, void* stream);
 int hd_limb_unpack_f32(const void* in, int64_t rows, int64_t cols, void* out, int64_t ld, void* stream);
-/* A stack of nn.Linear layers on a small batch (rows <= 512, widths <= 512) in ONE cooperative launch: MLP.forward /
+/* A stack of nn.Linear layers on a small batch (rows <= 512, widths <= 512) in ONE launch: MLP.forward /
  * Backbone.forward of ddpm.py:9-41 (config 3: 24 layers of width 512 at B = 200).  Layer i: y = x W_i^T + bias_i, then
  * epi 0 nothing, 1 erf-GELU, 2 x + GELU(y) (ddpm.py:20-22; d_in == d_out, not the first layer); add_emb != 0: y += emb[emb_idx[row]]
  * afterwards (ddpm.py:39, emb (emb_rows, d_out) fp32 contiguous; an index outside [0, emb_rows) gives a NaN row).  wimg
  * = hd_chain_pack_w_f32 of W_i (d_out, d_in) fp32 row-major, hd_chain_image_bytes(d_out, d_in) bytes, 16-byte aligned;
  * inner widths are multiples of 32.  Arithmetic as hd_gemm_limbs_f32 (3 bf16 limbs, fp32-faithful).  workspace:
  * hd_chain_workspace_bytes() bytes of device memory, 16-byte aligned, ZERO-FILLED ONCE by the caller when it is
- * allocated and from then on only passed to this function, private to the call while it runs (at most 31 layers).  The launch
- * is cooperative (hipLaunchCooperativeKernel: 256 workgroups resident at once) and never synchronises.  Every device-side
+ * allocated and from then on only passed to this function, private to the call while it runs (at most 31 layers).  The 256
+ * workgroups exchange data among themselves, so they must all be resident: an ordinary launch when the occupancy query says
+ * the grid fits the chip at once (HD_CHAIN_SMALL_LAUNCH=coop forces hipLaunchCooperativeKernel, which costs two cross-queue
+ * hand-overs per call); never two launches of it at once on one GPU.  It never synchronises.  Every device-side
  * wait is bounded (2 s); a launch in which one timed out writes NaN outputs -- that launch only: the kernel clears its
  * fail word when it leaves, the next launch on the workspace is clean.  hd_chain_failed(workspace, stream) returns 1 if
  * that happened in any launch since the last query and clears the report; it reads device memory, i.e. it synchronises
