@@ -302,6 +302,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
             const uint4 *a_n = nullptr, *w_n = nullptr;
 #ifdef HD_CHAIN_PHASE_PROBE
             unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, pt = wall_clock64(), pn;
+            const unsigned long long probe_c0 = clock64(), probe_w0 = pt;      // core clock against the 100 MHz wall clock
 #define HD_PH(k) { pn = wall_clock64(); ph[k] += pn - pt; pt = pn; }
 #else
 #define HD_PH(k)
@@ -418,7 +419,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
             HD_PH(5)
 #ifdef HD_CHAIN_PHASE_PROBE
             if (P.dbg && tid == 0)
+            {
                 for (int k = 0; k < 6; ++k) P.dbg[512 * 8 + 512 * 24 * 4 + (size_t)blockIdx.x * 8 + k] += ph[k];
+                P.dbg[512 * 8 + 512 * 24 * 4 + (size_t)blockIdx.x * 8 + 6] += clock64() - probe_c0;
+                P.dbg[512 * 8 + 512 * 24 * 4 + (size_t)blockIdx.x * 8 + 7] += wall_clock64() - probe_w0;
+            }
 #endif
             if (!stamped) HD_STAMP(2)
             if (P.dbg && tid == 0 && seq < 24) {

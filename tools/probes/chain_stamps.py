@@ -64,6 +64,11 @@ for dims, M in (([700, 512], 8192), ([700, 512], 15777), ([513, 800, 900, 800, 7
             print(f"  layer {l + 1}: {len(r):5d} tiles, K loop {np.median(r[:, 1]):6.2f} us median ({np.percentile(r[:, 1], 10):.2f}-{np.percentile(r[:, 1], 90):.2f}), "
                   f"write-out {np.median(r[:, 2]):5.2f} ({np.percentile(r[:, 2], 10):.2f}-{np.percentile(r[:, 2], 90):.2f}), gap to next {np.nanmedian(r[:, 3]):5.2f} "
                   f"({np.nanpercentile(r[:, 3], 10):.2f}-{np.nanpercentile(r[:, 3], 90):.2f}); starts {r[:, 4].min():.0f}-{r[:, 4].max():.0f} us")
+    clk = full[512 * 8 + 512 * 24 * 4:].reshape(512, 8)[:, 6:8].astype(np.float64)
+    if clk[:, 1].sum() > 0:
+        ghz = clk[:, 0] / np.maximum(clk[:, 1], 1) * 0.1
+        print(f"  core clock inside the K loops (s_memtime against the 100 MHz s_memrealtime): median {np.median(ghz):.3f} GHz "
+              f"({ghz.min():.3f}-{ghz.max():.3f})")
     if phases.sum() > 0:
         names = ["wait for the slab's LDS-DMA (vmcnt)", "barrier 1", "18 fragment reads + lgkmcnt(0)", "barrier 2", "staging issue + protocol", "48 MFMAs issued (+ write-out tail of the tile)"]
         tot = phases.sum(1)
