@@ -74,15 +74,15 @@ struct Layer {
     float* out_f32;          // fp32 output (M, N) with row pitch ldc, or null
     float* z_out;            // fp32 pre-activation (M, N) with row pitch ldc, or null (training forward)
     const float* aux;        // epi 3: fp32 z of the layer below (M, N) with row pitch ldc
-    int N, nslab, tiles_n, nslab_out, epi, ldc;
-    int wide;                // 1: column tiles of 128 (the last one narrow when <= 64 columns are left); 0: all tiles 64 wide
+    int N, nslab, nslab_out, epi, ldc;
+    int tiles_w, tiles_64;   // column tiles of a row block cut wide (128; the last one narrow when <= 64 columns are left) / narrow (64)
+    int narrow_from;         // row blocks from this one on are cut into narrow tiles (tiles_m: none, 0: all)
 };
 struct ChainArgs {
     Layer L[kMaxLayers];
     const uint4* A0;         // limb image of the input (M, K_0)
     unsigned* ws;
     int n_layers, M, tiles_m;
-    int cum[kMaxLayers + 1]; // cum[l] = column tiles of layers < l (per row block)
     int delay_ticks;         // start-up stagger of every second workgroup (0 = none)
     unsigned long long* dbg; // HD_MLP_CHAIN_DEBUG_PTR: 8 wall-clock stamps per workgroup (probes), or null
     int flags;               // debugging (HD_MLP_CHAIN_FLAGS): 4 = no pull-ahead (every successor resolved blocking), 8 = count slow paths
@@ -132,23 +132,57 @@ struct Item { int q, idx; };
 // queue q holds the row blocks q, q + 8, ...: nq of them, all layers
 __device__ __forceinline__ int queue_blocks(int q, int tiles_m) { return q < tiles_m ? (tiles_m - q + 7) >> 3 : 0; }
 
-// tab = {cum[0 .. kMaxLayers], tiles_n[0 .. kMaxLayers - 1]} in LDS: indexed by values that live in vector registers
-// (thread 0's successor bookkeeping), where an index into the kernel arguments would be a blocking global load
+// Column tiles of a layer: row blocks below the layer's `narrow_from` are cut into wide tiles (tw of them, numbered 0 ..),
+// the row blocks from there on into narrow ones (t64 of them, numbered kNarrow + 0 ..).  tab = {tw[l], t64[l], narrow_from[l]}
+// (three runs of kMaxLayers) plus the eight queue lengths, in LDS: indexed by values that live in vector registers (thread
+// 0's successor bookkeeping), where an index into the kernel arguments would be a blocking global load.
+constexpr int kNarrow = 1 << 20;
+constexpr int TAB_TW = 0, TAB_T64 = kMaxLayers, TAB_NF = 2 * kMaxLayers, TAB_QLEN = 3 * kMaxLayers, TAB_SIZE = 3 * kMaxLayers + 8;
+// wide row blocks of layer l in queue q (which holds nq row blocks)
+__device__ __forceinline__ int wide_blocks(const int* tab, int l, int q, int nq) {
+    const int n = (tab[TAB_NF + l] - q + 7) >> 3;
+    return n < 0 ? 0 : (n > nq ? nq : n);
+}
+__device__ __forceinline__ int queue_items(const int* tab, int n_layers, int tiles_m, int q) {
+    const int nq = queue_blocks(q, tiles_m);
+    int n = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        const int nw = wide_blocks(tab, l, q, nq);
+        n += nw * tab[TAB_TW + l] + (nq - nw) * tab[TAB_T64 + l];
+    }
+    return n;
+}
 __device__ __forceinline__ void decode(const int* tab, int n_layers, int tiles_m, int q, int idx, int& l, int& rb, int& tn) {
     const int nq = queue_blocks(q, tiles_m);
-    l = 0;
-    while (l + 1 < n_layers && idx >= nq * tab[l + 1]) ++l;
-    const int rem = idx - nq * tab[l];
-    const int tnn = tab[kMaxLayers + 1 + l];
-    const int j = rem / tnn;
-    tn = rem - j * tnn;
+    int nw = 0;
+    for (l = 0;; ++l) {
+        nw = wide_blocks(tab, l, q, nq);
+        const int items = nw * tab[TAB_TW + l] + (nq - nw) * tab[TAB_T64 + l];
+        if (idx < items || l + 1 >= n_layers) break;
+        idx -= items;
+    }
+    const int tw = tab[TAB_TW + l], t64 = tab[TAB_T64 + l];
+    int j;
+    if (idx < nw * tw) {
+        j = idx / tw;
+        tn = idx - j * tw;
+    } else {
+        const int r = idx - nw * tw;
+        j = r / t64;
+        tn = kNarrow + r - j * t64;
+        j += nw;
+    }
     rb = q + 8 * j;
 }
+// tiles of (layer l, row block rb): what the counter of that row block must reach
+__device__ __forceinline__ int tiles_of(const int* tab, int l, int rb) {
+    return rb < tab[TAB_NF + l] ? tab[TAB_TW + l] : tab[TAB_T64 + l];
+}
 
-// one lane: the counter of (layer l - 1, row block rb) has reached that layer's tile count, or the launch has failed
+// one lane: the counter of (layer l - 1, row block rb) has reached that row block's tile count, or the launch has failed
 __device__ __forceinline__ bool dep_ready(const ChainArgs& P, const int* tab, int l, int rb) {
     if (l == 0) return true;
-    return ld_agent(P.ws + WS_DONE + (l - 1) * P.tiles_m + rb) >= (unsigned)tab[kMaxLayers + l];
+    return ld_agent(P.ws + WS_DONE + (l - 1) * P.tiles_m + rb) >= (unsigned)tiles_of(tab, l - 1, rb);
 }
 
 // Measured and not kept (same box, 501 us per chain as it is): the nine staging pieces of a wavefront dealt between the
@@ -162,7 +196,7 @@ __device__ __forceinline__ bool dep_ready(const ChainArgs& P, const int* tab, in
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void mlp_chain(const ChainArgs P) {
     __shared__ uint4 lds[CH_BUF];
     __shared__ int nxt_s[8];                                  // successor: {queue, index, ready, layer, row block, column tile}
-    __shared__ int tab[2 * kMaxLayers + 2];
+    __shared__ int tab[TAB_SIZE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int r16 = lane & 15, kq = lane >> 4;
@@ -172,13 +206,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     // HW_REG_XCC_ID (id 20), bits 3:0: the XCD this workgroup runs on; locality only, never correctness
     const int my_xcd = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u);
 
-    if (threadIdx.x <= kMaxLayers) tab[threadIdx.x] = P.cum[threadIdx.x < (unsigned)P.n_layers ? threadIdx.x : P.n_layers];
-    if (threadIdx.x < kMaxLayers) tab[kMaxLayers + 1 + threadIdx.x] = threadIdx.x < (unsigned)P.n_layers ? P.L[threadIdx.x].tiles_n : 1;
+    if (threadIdx.x < kMaxLayers) {
+        const bool used = threadIdx.x < (unsigned)P.n_layers;
+        tab[TAB_TW + threadIdx.x] = used ? P.L[threadIdx.x].tiles_w : 1;
+        tab[TAB_T64 + threadIdx.x] = used ? P.L[threadIdx.x].tiles_64 : 1;
+        tab[TAB_NF + threadIdx.x] = used ? P.L[threadIdx.x].narrow_from : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) tab[TAB_QLEN + threadIdx.x] = queue_items(tab, P.n_layers, P.tiles_m, threadIdx.x);
     __syncthreads();
     // ---- thread 0's private scheduling state ----
     int curq = my_xcd, tried = 0;                             // queue being pulled from, queues found empty so far
-    const int items_per_block = P.cum[P.n_layers];
-    auto qlen = [&](int q) { return queue_blocks(q, tiles_m) * items_per_block; };
+    auto qlen = [&](int q) { return tab[TAB_QLEN + q]; };
     // blocking pull (start of the launch, end of a queue): next item of the first non-empty queue from curq on
     auto pull_blocking = [&]() -> Item {
         unsigned head[8];
@@ -259,12 +298,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
             }                                                                               \
         }                                                                                   \
     }
-    auto tile_kind = [&](int l, int tn) { return P.L[l].wide ? (P.L[l].N - tn * BNT <= 64 ? 1 : 0) : 1 + (tn & 1); };
+    auto tile_kind = [&](int l, int tn) { return tn < kNarrow ? (P.L[l].N - tn * BNT <= 64 ? 1 : 0) : 1 + (tn & 1); };
     auto a_src = [&](int l, int rb) {
         const uint4* base = l == 0 ? P.A0 : P.L[l - 1].out_img;
         return base + (size_t)rb * P.L[l].nslab * kTile + lane;
     };
-    auto w_src = [&](int l, int tn) { return P.L[l].W + (size_t)(P.L[l].wide ? tn : tn >> 1) * P.L[l].nslab * kTile + lane; };
+    auto w_src = [&](int l, int tn) { return P.L[l].W + (size_t)(tn < kNarrow ? tn : (tn - kNarrow) >> 1) * P.L[l].nslab * kTile + lane; };
 
     HD_STAMP(1)
     int stamped = 0;
@@ -387,7 +426,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                             else { addr = ws + WS_DONE + (p_l - 1) * tiles_m + p_rb; p_state = 3; }   // poll = add 0
                         }
                     } else {
-                        if (p_state == 3 && got >= (unsigned)tab[kMaxLayers + p_l]) {
+                        if (p_state == 3 && got >= (unsigned)tiles_of(tab, p_l - 1, p_rb)) {
                             p_ready = 1;
                             // agent acquire for the successor's A operand: invalidate this CU's L1; the vmcnt(0) at the top of
                             // the next slab waits for it, the barrier behind that orders the other wavefronts' loads
@@ -432,7 +471,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
             }
             // ---- write-out of the C^T tile: a lane owns row m and columns nb .. nb + 3 of accumulator (i, j) ----
             {
-                const int m0 = rb * 128, n0 = Ly.wide ? tn * BNT + (narrow ? wc * 32 : wc * 64) : tn * 64 + wc * 32;
+                const int m0 = rb * 128, n0 = tn < kNarrow ? tn * BNT + (narrow ? wc * 32 : wc * 64) : (tn - kNarrow) * 64 + wc * 32;
                 const int N = Ly.N, epi = Ly.epi, ldc = Ly.ldc;
                 const float* __restrict__ bias = Ly.bias;
                 uint4* __restrict__ CL = Ly.out_img;
@@ -645,13 +684,14 @@ extern "C" int hd_mlp_chain_limbs_f32(const void* A0, int64_t rows, const hd_mlp
     P.n_layers = n_layers;
     P.M = (int)rows;
     P.tiles_m = (int)((rows + 127) / 128);
-    struct Knobs { int n_cu, delay_ns, flags, reload, per_cu; };
+    struct Knobs { int n_cu, delay_ns, flags, reload, per_cu, tail; };
     static Knobs knobs = [] {
-        Knobs k{256, 0, 0, 0, 2};
+        Knobs k{256, 0, 0, 0, 2, 0};
         if (const char* e = getenv("HD_MLP_CHAIN_PER_CU")) k.per_cu = atoi(e);
         if (const char* e = getenv("HD_MLP_CHAIN_DELAY_NS")) k.delay_ns = atoi(e);
         if (const char* e = getenv("HD_MLP_CHAIN_FLAGS")) k.flags = atoi(e);
         if (const char* e = getenv("HD_GEMM_TUNE_RELOAD")) k.reload = atoi(e);
+        if (const char* e = getenv("HD_MLP_CHAIN_TAIL")) k.tail = atoi(e);
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -662,7 +702,9 @@ extern "C" int hd_mlp_chain_limbs_f32(const void* A0, int64_t rows, const hd_mlp
         if (const char* e = getenv("HD_MLP_CHAIN_DELAY_NS")) knobs.delay_ns = atoi(e);
         if (const char* e = getenv("HD_MLP_CHAIN_FLAGS")) knobs.flags = atoi(e);
         if (const char* e = getenv("HD_MLP_CHAIN_PER_CU")) knobs.per_cu = atoi(e);
+        if (const char* e = getenv("HD_MLP_CHAIN_TAIL")) knobs.tail = atoi(e);
     }
+    if (knobs.tail < 0 || knobs.tail > 100) knobs.tail = 0;
     const int per_cu = knobs.per_cu >= 1 && knobs.per_cu <= 2 ? knobs.per_cu : 2;
     const int64_t grid_full = (int64_t)knobs.n_cu * per_cu / 8 * 8 > 8 ? (int64_t)knobs.n_cu * per_cu / 8 * 8 : 8;
     int64_t items = 0;
@@ -692,27 +734,30 @@ extern "C" int hd_mlp_chain_limbs_f32(const void* A0, int64_t rows, const hd_mlp
         L.aux = s.epi == 3 ? (const float*)s.aux : nullptr;
         L.N = (int)s.N;
         L.nslab = (int)((s.K + 31) / 32);
-        // Every layer wide by default.  Narrow (64-wide) tiles for the whole LAST layer when its wide tiles are fewer than
-        // two per workgroup (flag 16: the launch ends on that layer, and tiles of half the length leave the workgroups
-        // idle for half as long at the end) measured 467 against 460 us, inside the noise, so it is not the default;
-        // flag 32 = every layer narrow (the 128 x 64 tiling of csrc/gemm_limbs.hip): 521 us on the same box.
-        const int64_t wide_tiles = (s.N + BNT - 1) / BNT * P.tiles_m;
-        L.wide = (knobs.flags & 32) ? 0 : !((knobs.flags & 16) && last && n_layers > 1 && wide_tiles < 2 * grid_full);
-        L.tiles_n = (int)(L.wide ? (s.N + BNT - 1) / BNT : (s.N + 63) / 64);
+        // Wide tiles everywhere by default.  HD_MLP_CHAIN_TAIL = t cuts the last t percent of the LAST layer's row blocks
+        // (the items handed out last) into narrow tiles of half the length, so that the workgroups leave closer together
+        // (with wide tiles they leave over a span of ~70 us).  Measured at t = 0 / 15 / 25 / 33 / 50 / 100: 452 / 455 / 452 /
+        // 451 / 448 / 451 us per chain (tools/probes/chain_tail.py, alternating, same box): nothing outside the noise --
+        // narrow tiles multiply at 85 % of the wide rate, which eats what the shorter drain gives -- so t = 0.
+        // flag 32 = every layer narrow (the 128 x 64 tiling of csrc/gemm_limbs.hip): 521 us.
+        L.tiles_w = (int)((s.N + BNT - 1) / BNT);
+        L.tiles_64 = (int)((s.N + 63) / 64);
+        L.narrow_from = P.tiles_m;
+        if (knobs.flags & 32) L.narrow_from = 0;
+        else if (last && n_layers > 1)
+            L.narrow_from = (int)(P.tiles_m - (int64_t)P.tiles_m * knobs.tail / 100);
+        items += (int64_t)L.narrow_from * L.tiles_w + (int64_t)(P.tiles_m - L.narrow_from) * L.tiles_64;
         L.nslab_out = (int)((s.N + 31) / 32);
         L.epi = s.epi;
         L.ldc = (int)(f32io ? s.ldc : s.N);
-        P.cum[i] = (int)items;
-        items += L.tiles_n;
     }
-    P.cum[n_layers] = (int)items;
-    HD_REQUIRE(items * ((P.tiles_m + 7) / 8) < (1LL << 30), "hd_mlp_chain_limbs_f32: too many tiles");
+    HD_REQUIRE(items < (1LL << 30), "hd_mlp_chain_limbs_f32: too many tiles");
     P.delay_ticks = knobs.delay_ns / 10;
     P.flags = knobs.flags;
     P.dbg = nullptr;
     if (knobs.reload)
         if (const char* e = getenv("HD_MLP_CHAIN_DEBUG_PTR")) P.dbg = (unsigned long long*)strtoull(e, nullptr, 0);
-    const int64_t total = items * P.tiles_m;
+    const int64_t total = items;
     // The kernel's registers (252) admit two workgroups per CU, its LDS (48 KB) three; unused dynamic LDS pads the
     // footprint so that exactly `per_cu` workgroups fit a CU (160 KB) and the grid fills the chip evenly.
     int64_t grid = grid_full;

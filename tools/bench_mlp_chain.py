@@ -30,7 +30,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=15777)
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--flags", default="8,24,40", help="HD_MLP_CHAIN_FLAGS values to time")
+    ap.add_argument("--flags", default="8,40", help="HD_MLP_CHAIN_FLAGS values to time")
     a = ap.parse_args()
     M, dims = a.rows, [513, 800, 900, 800, 700, 512]
     torch.manual_seed(0)
