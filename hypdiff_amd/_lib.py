@@ -112,7 +112,7 @@ SIGNATURES = {
     "hd_adj_fill": [P, P, P, I64, P, c_int, P, P, P, P],
     "hd_feat_normalize": [P, c_int, I64, I64, P, P],
     "hd_spmm_csr*": [P, P, P, P, P, I64, I64, P, I64, P],
-    "hd_spmm_csr_strided*": [P, P, P, P, I64, P, I64, I64, I64, P, I64, P],
+    "hd_spmm_csr_strided*": [P, P, P, P, I64, P, I64, I64, I64, P, I64, I64, P],
     "hd_pb_agg*": _agg, "hd_hb_agg*": _agg,
     "hd_gemm_f32": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, c_int, P],
     "hd_gemm_f64": [P, P, P, P, I64, I64, I64, I64, I64, I64, P],

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 ? 4 : 1)) void spmm_rows(co
                     ok4[r] = row < n;
                     if (ok4[r]) {
                         const int rs = rowptr[row], re = rowptr[row + 1];
-                        if ((skip_long & 1) && re - rs > kLongRow) ok4[r] = false;
+                        if ((skip_long & 1) && re - rs > (skip_long >> 8)) ok4[r] = false;
                         else
                             for (int base = rs; base < re; base += 64) {
                                 const int cnt = re - base < 64 ? re - base : 64;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 ? 4 : 1)) void spmm_rows(co
         }
         for (int64_t row = (int64_t)blockIdx.x * RPB + (threadIdx.x >> 6); row < n; row += (int64_t)gridDim.x * RPB) {
             const int rs = rowptr[row], re = rowptr[row + 1];
-            if ((skip_long & 1) && re - rs > kLongRow) continue;
+            if ((skip_long & 1) && re - rs > (skip_long >> 8)) continue;
             acc.zero();
             for (int base = rs; base < re; base += 64) {
                 const int cnt = re - base < 64 ? re - base : 64;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kBlock, (sizeof(T) == 4 ? 4 : 1)) void spmm_rows(co
         bool valid = row < n;
         int rs = 0, re = 0;
         if (valid) { rs = rowptr[row]; re = rowptr[row + 1]; }
-        if ((skip_long & 1) && re - rs > kLongRow) { valid = false; re = rs; }
+        if ((skip_long & 1) && re - rs > (skip_long >> 8)) { valid = false; re = rs; }
         const int seg0 = rowptr[r0], seg1 = rowptr[r1];
         acc.zero();
         if (seg1 - seg0 <= kStage) {
@@ -239,7 +239,8 @@ __global__ __launch_bounds__(kLongWaves * 64) void spmm_long(const int32_t* __re
 template <class M, typename T>
 int launch_spmm(const char* name, const int32_t* rowptr, const int32_t* col, const void* val, const void* x,
                 void* out, int64_t n, int64_t d, int epi, hd_curv ci, hd_curv co, int act,
-                const int32_t* long_rows, int64_t n_long, void* st, int64_t ldx = 0, int64_t ldo = 0, int form = 0) {
+                const int32_t* long_rows, int64_t n_long, void* st, int64_t ldx = 0, int64_t ldo = 0, int form = 0,
+                int long_thr = 0) {
     HD_REQUIRE(n >= 0 && d >= 1, "%s: bad shape rows=%lld dim=%lld", name, (long long)n, (long long)d);
     if (ldx == 0) ldx = d;                              // row pitches (elements); 0 = contiguous rows
     if (ldo == 0) ldo = d;
@@ -267,7 +268,12 @@ int launch_spmm(const char* name, const int32_t* rowptr, const int32_t* col, con
     // graph takes (hypdiff_amd/dist.py) -- and 0 decides from this launch's own rows.
     HD_REQUIRE(form >= 0 && form <= 2, "%s: form must be 0 (auto), 1 or 2", name);
     const bool four = form == 2 || (form == 0 && rows4 && n >= 8192 && (!IsHB<M>::value || n_long == 0));
-    const int row_flags = (n_long > 0 ? 1 : 0) | (four ? 2 : 0);
+    // long_thr: rows with MORE entries are in `long_rows` and taken by spmm_long (0 = kLongRow).  A small graph passes a
+    // lower threshold (hypdiff_amd/ops.py): there one wavefront walking a row of a few hundred neighbours is the whole
+    // launch's critical path (config 4: 42 us for 2708 rows), and eight wavefronts with the fixed-shape sum are not.
+    if (long_thr <= 0) long_thr = kLongRow;
+    HD_REQUIRE(long_thr >= 8 && long_thr < (1 << 20), "%s: long-row threshold out of range", name);
+    const int row_flags = (n_long > 0 ? 1 : 0) | (four ? 2 : 0) | (long_thr << 8);
     int rc = dispatch_cfg<T>(c, [&](auto g, auto v) {
         constexpr int G = decltype(g)::value, V = decltype(v)::value;
         constexpr int R0 = V < 4 ? 4 : V;              // smallest specialisation
@@ -318,10 +324,12 @@ int launch_spmm(const char* name, const int32_t* rowptr, const int32_t* col, con
     }                                                                                                      \
     extern "C" int hd_spmm_csr_strided_##sfx(const int32_t* rowptr, const int32_t* col, const void* val,  \
                                              const void* x, int64_t ldx, void* out, int64_t ldo, int64_t n,  \
-                                             int64_t d, const int32_t* long_rows, int64_t n_long, void* st) { \
+                                             int64_t d, const int32_t* long_rows, int64_t n_long,          \
+                                             int64_t long_threshold, void* st) {                           \
         hd_curv one{1, 1, 1, 1};                                                                           \
+        HD_REQUIRE(long_threshold >= 0 && long_threshold < (1 << 20), "hd_spmm_csr_strided: bad long-row threshold"); \
         return hd::launch_spmm<hd::PB<T>, T>("hd_spmm_csr_strided_" #sfx, rowptr, col, val, x, out, n, d, hd::E_NONE, \
-                                             one, one, 0, long_rows, n_long, st, ldx, ldo);                \
+                                             one, one, 0, long_rows, n_long, st, ldx, ldo, 0, (int)long_threshold); \
     }                                                                                                      \
     extern "C" int hd_pb_agg_##sfx(const int32_t* rowptr, const int32_t* col, const void* val,            \
                                    const void* xt, void* out, int64_t n, int64_t d, hd_curv c_in,          \
@@ -329,7 +337,7 @@ int launch_spmm(const char* name, const int32_t* rowptr, const int32_t* col, con
                                    int64_t n_long, void* st) {                                             \
         return hd::launch_spmm<hd::PB<T>, T>("hd_pb_agg_" #sfx, rowptr, col, val, xt, out, n, d,          \
                                              (fuse_act & 1) ? hd::E_AGG_ACT : hd::E_AGG, c_in, c_out, act, \
-                                             long_rows, n_long, st, 0, 0, (fuse_act >> 8) & 3);            \
+                                             long_rows, n_long, st, 0, 0, (fuse_act >> 8) & 3, (fuse_act >> 10) & 0xfffff); \
     }                                                                                                      \
     extern "C" int hd_hb_agg_##sfx(const int32_t* rowptr, const int32_t* col, const void* val,            \
                                    const void* xt, void* out, int64_t n, int64_t d, hd_curv c_in,          \
@@ -337,5 +345,5 @@ int launch_spmm(const char* name, const int32_t* rowptr, const int32_t* col, con
                                    int64_t n_long, void* st) {                                             \
         return hd::launch_spmm<hd::HB<T>, T>("hd_hb_agg_" #sfx, rowptr, col, val, xt, out, n, d,          \
                                              (fuse_act & 1) ? hd::E_AGG_ACT : hd::E_AGG, c_in, c_out, act, \
-                                             long_rows, n_long, st, 0, 0, (fuse_act >> 8) & 3);            \
+                                             long_rows, n_long, st, 0, 0, (fuse_act >> 8) & 3, (fuse_act >> 10) & 0xfffff); \
     }

@@ -572,9 +572,11 @@ def shard_aggregate_slabs(layer, csr, slabs, n_loc):
     d = slabs[-1][1]
     full0 = slabs[0][2]
     sup = torch.empty(csr.shape[0], d, dtype=full0.dtype, device=full0.device)
+    whole = getattr(csr, "whole", None)
+    thr = ops.agg_long_threshold(whole[0] if whole is not None else csr.shape[0])     # as the fused aggregate (ops.agg)
     for lo, hi, full, work in slabs:
         _timed_wait("allgather", [work], full.is_cuda)   # the compute stream waits for THIS slab's collective only
-        ops.spmm_into(csr, full, sup, lo)
+        ops.spmm_into(csr, full, sup, lo, long_thr=thr)
     out = ops.agg_tail(man.abi, sup, layer.agg.c, layer.hyp_act.c_out if code is not None else None, code)
     if code is None:
         out = layer.hyp_act.forward(out)

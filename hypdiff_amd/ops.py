@@ -707,6 +707,17 @@ class CSR:
     def values(self, dtype):
         return self.val if self.val.dtype == dtype else self.val.to(dtype)
 
+    def long_rows_above(self, thr):
+        """(rows with more than `thr` entries, their count) -- LONG_ROW's list, or one built once for a lower threshold"""
+        if thr == self.LONG_ROW:
+            return self.long_rows, self.n_long
+        cache = self.__dict__.setdefault("_long_by_thr", {})
+        if thr not in cache:
+            deg = self.rowptr[1:] - self.rowptr[:-1]
+            rows = (deg > thr).nonzero().flatten().to(torch.int32).contiguous()
+            cache[thr] = (rows, int(rows.numel()))
+        return cache[thr]
+
     def transposed(self):
         """CSR of adj^T (backward of torch.spmm w.r.t. its dense operand), built once."""
         t = getattr(self, "_t", None)
@@ -772,17 +783,20 @@ def spmm(csr, x):
     return out
 
 
-def spmm_into(csr, x, out, col0):
+def spmm_into(csr, x, out, col0, long_thr=None):
     """out[:, col0:col0 + x.shape[1]] = adj @ x for a column slab x (contiguous) of wider rows
-    (hd_spmm_csr_strided: same per-column summation order as spmm on whole rows)."""
+    (hd_spmm_csr_strided: same per-column summation order as spmm on whole rows).  long_thr: the long-row threshold
+    of the aggregate this slab is a part of (agg_long_threshold of the whole graph); None = CSR.LONG_ROW."""
     _dev(x, out)
     assert x.is_contiguous() and out.is_contiguous() and out.dtype == x.dtype and out.shape[0] == csr.shape[0]
     w = x.shape[1]
     assert 0 <= col0 and col0 + w <= out.shape[1]
     dst = out[:, col0:]
+    thr = CSR.LONG_ROW if long_thr is None else long_thr
+    long_rows, n_long = csr.long_rows_above(thr)
     _lib.call("hd_spmm_csr_strided" + _sfx(x), _p(csr.rowptr), _p(csr.col), _p(csr.values(x.dtype)), _p(x), w,
               ctypes.c_void_p(dst.data_ptr()), out.shape[1], csr.shape[0], w,
-              _p(csr.long_rows) if csr.n_long else None, csr.n_long, _stream())
+              _p(long_rows) if n_long else None, n_long, thr, _stream())
     return out
 
 
@@ -856,6 +870,15 @@ def agg_tail(manifold, s, c_in, c_out=None, act_code=None):
 
 
 AGG_FOUR_ROW_MIN = 8192          # csrc/hd_spmm.cuh: from this many rows the fused tail runs four rows per wavefront
+AGG_MID_ROW = 64                 # long-row threshold of the fused aggregate for graphs below AGG_FOUR_ROW_MIN rows
+
+
+def agg_long_threshold(n_rows):
+    """Rows with more entries than this are summed by a workgroup in 8 fixed slices instead of by one wavefront in CSR
+    order (rounding-level difference).  A small graph's launch is as long as its longest one-wavefront row (config 4:
+    42 us for 2708 rows, a row of several hundred neighbours), so there the threshold is 64; a property of the WHOLE
+    graph, like agg_form."""
+    return AGG_MID_ROW if n_rows < AGG_FOUR_ROW_MIN else CSR.LONG_ROW
 
 
 def agg_form(manifold, n_rows, n_long):
@@ -875,10 +898,12 @@ def agg(manifold, csr, xt, c_in, c_out=None, act_code=None):
     fuse = act_code is not None
     whole = getattr(csr, "whole", None)
     form = agg_form(manifold, *whole) if whole is not None else 0
+    thr = agg_long_threshold(whole[0] if whole is not None else csr.shape[0])
+    long_rows, n_long = csr.long_rows_above(thr)
     _lib.call(f"hd_{manifold}_agg" + _sfx(x2), _p(csr.rowptr), _p(csr.col), _p(csr.values(x2.dtype)), _p(x2),
               _p(out), csr.shape[0], x2.shape[1], curv(c_in), curv(c_out if fuse else c_in),
-              act_code if fuse else 0, (1 if fuse else 0) | (form << 8), _p(csr.long_rows) if csr.n_long else None,
-              csr.n_long, _stream())
+              act_code if fuse else 0, (1 if fuse else 0) | (form << 8) | (thr << 10), _p(long_rows) if n_long else None,
+              n_long, _stream())
     return out
 
 

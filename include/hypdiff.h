@@ -222,15 +222,22 @@ HD_DECL2(hd_spmm_csr, const int32_t* rowptr, const int32_t* col, const void* val
  * 16-byte loads when both are multiples of 4 (f32) / 2 (f64) and the bases are aligned).  A feature column's sum
  * does not depend on the other columns, so spmm over column slabs == spmm over whole rows bit for bit: this is
  * what lets a row-sharded HypAgg start on the first slab of the all-gathered tangent rows while the next slab is
- * still on the wire (hypdiff_amd/dist.py). */
+ * still on the wire (hypdiff_amd/dist.py).  long_threshold: the threshold `long_rows` was built with (rows with MORE
+ * entries; 0 = 512) -- the same one the fused aggregate of the whole graph takes (hd_*_agg, fuse_act bits 10-29), so
+ * that the slab path sums every row in the same shape. */
 HD_DECL2(hd_spmm_csr_strided, const int32_t* rowptr, const int32_t* col, const void* val, const void* x, int64_t ldx,
-         void* out, int64_t ldo, int64_t rows, int64_t dim, const int32_t* long_rows, int64_t n_long, void* stream)
+         void* out, int64_t ldo, int64_t rows, int64_t dim, const int32_t* long_rows, int64_t n_long,
+         int64_t long_threshold, void* stream)
 /* proj(expmap0(spmm(adj, xt))) :150-151, xt = logmap0(x) already in the tangent space (:134);
  * fuse_act bit 0 appends HypAct.forward (:170-173) with (c_in, c_out, act) in the same pass.  Bits 8-9 of fuse_act pin
  * the form of the fused row tail, which has two evaluation orders that differ by rounding: 0 = chosen from this
  * call's rows (four rows per wavefront from 8192 rows on; on the hyperboloid only without long rows), 1 = one row per
  * wavefront, 2 = four rows per wavefront.  A row shard of a larger graph passes the form the whole graph takes, so
- * that sharded and unsharded encodes agree bit for bit. */
+ * that sharded and unsharded encodes agree bit for bit.  Bits 10-29 of fuse_act: the long-row threshold T the caller
+ * built `long_rows` with (rows with MORE than T entries; 0 = 512).  Long rows are summed by a workgroup in 8 fixed
+ * slices (bit-reproducible; differs from the sequential sum by rounding only), so T too is a property of the adjacency:
+ * hypdiff_amd passes 64 for graphs of fewer than 8192 rows, where one wavefront walking a row of a few hundred neighbours
+ * is the launch's critical path, and 512 otherwise; a row shard passes the whole graph's. */
 HD_DECL2(hd_pb_agg, const int32_t* rowptr, const int32_t* col, const void* val, const void* xt, void* out,
          int64_t rows, int64_t dim, hd_curv c_in, hd_curv c_out, int act, int fuse_act,
          const int32_t* long_rows, int64_t n_long, void* stream)
