@@ -127,3 +127,28 @@ def test_training_stack_through_the_chain_equals_per_layer_launches(rows, dims, 
     for a, b in zip(g0, g1):
         assert torch.equal(a, b), float((a - b).abs().max())
     assert not ops.mlp_chain_failed()
+
+
+def test_two_chains_at_once_on_two_streams():
+    """Two launches in flight on one GPU, each with its own workspace (one per stream): no wait of the kernel depends on
+    residency (an item depends only on items handed out before it), so they may share the CUs in any proportion."""
+    from hypdiff_amd import ops
+    dev = "cuda:0"
+    torch.manual_seed(2)
+    dims = [65, 200, 136, 72]
+    xs = [torch.randn(6000, dims[0], device=dev), torch.randn(9000, dims[0], device=dev)]
+    layers = _layers(dims, 11, dev)
+    imgs = [ops.limb_pack(x) for x in xs]
+    refs = [_per_layer(ops, a, layers) for a in imgs]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    outs = [[], []]
+    for rep in range(4):
+        for k, s in enumerate(streams):
+            with torch.cuda.stream(s):
+                outs[k].append(ops.mlp_chain(imgs[k], layers))
+    torch.cuda.synchronize()
+    for k in range(2):
+        for got in outs[k]:
+            assert torch.equal(got, refs[k])
+    assert not ops.mlp_chain_failed()
