@@ -76,6 +76,7 @@ SIGNATURES = {
     "hd_pb_proj*": _map1, "hd_pb_expmap0*": _map1, "hd_pb_logmap0*": _map1, "hd_pb_expmap0_proj*": _map1,
     "hd_pb_mobius_add*": _map2, "hd_pb_expmap*": _map2, "hd_pb_logmap*": _map2,
     "hd_pb_logmap_at*": _at, "hd_pb_expmap_at*": _at, "hd_pb_sqdist*": _map2,
+    "hd_pb_logmap_at_f32_f64": _at,
     "hd_pb_matvec_epilogue*": [P, P, P, I64, I64, HdCurv, c_int, P],
     "hd_pb_hyp_act*": _act,
     "hd_pb_vae_hnn_tail*": [P, P, P, P, P, I64, I64, HdCurv, c_double, c_int, c_int, P],

@@ -128,6 +128,27 @@ struct Tile {
             }
         }
     }
+    // load a row kept in memory as a NARROWER type (fp32 rows into an fp64 tile): the same values as a cast pass
+    // followed by load(), without the (N, d) intermediate
+    template <typename S>
+    __device__ __forceinline__ void load_cvt(const S* __restrict__ row) {
+#pragma unroll
+        for (int k = 0; k < CHMAX; ++k) {
+            const int c0 = (k * G + j) * VEC;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[k * VEC + e] = T(0);
+            if (k < ch && c0 < d) {
+                if constexpr (VEC == 2 && sizeof(S) == 4) {
+                    const float2 t = *reinterpret_cast<const float2*>(row + c0);
+                    v[k * VEC] = (T)t.x;
+                    v[k * VEC + 1] = (T)t.y;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[k * VEC + e] = (T)row[c0 + e];
+                }
+            }
+        }
+    }
     __device__ __forceinline__ void zero() {
 #pragma unroll
         for (int i = 0; i < kRegs; ++i) v[i] = T(0);

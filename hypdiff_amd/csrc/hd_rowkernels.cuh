@@ -85,9 +85,10 @@ __global__ __launch_bounds__(kBlock) void row_map1(const T* __restrict__ in, T* 
 }
 
 // out[row] = op(a[row or gathered], b[row]); ia (optional) gathers rows of a
-template <class Op, typename T, typename I, int G, int VEC, int REGS>
+// (TB: the type b is stored in -- T, or float for an fp64 map of fp32 rows, widened on load)
+template <class Op, typename T, typename I, int G, int VEC, int REGS, typename TB = T>
 __global__ __launch_bounds__(kBlock) void row_map2(const T* __restrict__ a, const I* __restrict__ ia,
-                                                   const T* __restrict__ b, T* __restrict__ out,
+                                                   const TB* __restrict__ b, T* __restrict__ out,
                                                    int64_t n, int d, Op op, int64_t na) {
     constexpr int RPB = kBlock / G, R = kRegs / REGS;
     Tile<T, G, VEC, REGS> x[R], y[R];
@@ -103,7 +104,8 @@ __global__ __launch_bounds__(kBlock) void row_map2(const T* __restrict__ a, cons
             int64_t ra = ia ? (int64_t)ia[rl] : rl;
             if (ia) ra = ra < 0 ? 0 : (ra >= na ? na - 1 : ra);      // a label outside the table must not fault
             x[i].load(a + ra * d);
-            y[i].load(b + rl * d);
+            if constexpr (sizeof(TB) == sizeof(T)) y[i].load(reinterpret_cast<const T*>(b) + rl * d);
+            else y[i].load_cvt(b + rl * d);
         }
 #pragma unroll
         for (int i = 0; i < R; ++i) op(x[i], y[i], row[i] < n ? row[i] : n - 1);      // result left in y
@@ -191,8 +193,8 @@ inline int launch_map1(const char* name, const T* in, T* out, int64_t n, int64_t
     });
 }
 
-template <typename T, typename I, class Op>
-inline int launch_map2(const char* name, const T* a, const I* ia, const T* b, T* out, int64_t n, int64_t d,
+template <typename T, typename I, class Op, typename TB = T>
+inline int launch_map2(const char* name, const T* a, const I* ia, const TB* b, T* out, int64_t n, int64_t d,
                        Op op, hipStream_t st, int64_t na = 0) {
     HD_REQUIRE(n >= 0 && d >= 1, "%s: bad shape rows=%lld dim=%lld", name, (long long)n, (long long)d);
     if (n == 0) return HD_OK;
@@ -201,8 +203,8 @@ inline int launch_map2(const char* name, const T* a, const I* ia, const T* b, T*
     HD_REQUIRE(c.ok, "%s: dim=%lld exceeds the register-tile limit", name, (long long)d);
     return dispatch_cfg_regs<T>(c, pick_regs<T>(c, n, d), [&](auto g, auto v, auto rg) {
         constexpr int G = decltype(g)::value, V = decltype(v)::value, RG = decltype(rg)::value;
-        row_map2<Op, T, I, G, V, RG><<<grid_for_rows_batched(n, G, kRegs / RG), kBlock, 0, st>>>(a, ia, b, out, n,
-                                                                                               (int)d, op, na);
+        row_map2<Op, T, I, G, V, RG, TB><<<grid_for_rows_batched(n, G, kRegs / RG), kBlock, 0, st>>>(a, ia, b, out, n,
+                                                                                                   (int)d, op, na);
         return check_launch(name);
     });
 }

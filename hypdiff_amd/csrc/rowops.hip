@@ -256,6 +256,15 @@ HD_MAP2(hd_pb_logmap, B_LOGMAP)      // a = p1 (base point), b = p2
     }
 HD_MAP2_AT(hd_pb_expmap_at, B_EXPMAP)
 HD_MAP2_AT(hd_pb_logmap_at, B_LOGMAP)
+// logmap at the centres of fp32 rows in fp64 (diffusion.forward :350-352 on encoder output: x.double() first): the rows
+// are widened on load -- the same bits as a cast pass followed by hd_pb_logmap_at_f64, one (N, d) fp64 pass fewer
+extern "C" int hd_pb_logmap_at_f32_f64(const void* centres, const int32_t* labels, int64_t k, const void* b, void* out,
+                                       int64_t n, int64_t d, hd_curv c, void* st) {
+    HD_REQUIRE(labels && k >= 1, "hd_pb_logmap_at_f32_f64: labels/centres missing");
+    return launch_map2<double, int32_t, Op2<double, B_LOGMAP>, float>("hd_pb_logmap_at_f32_f64", (const double*)centres, labels,
+                                                                     (const float*)b, (double*)out, n, d,
+                                                                     Op2<double, B_LOGMAP>{mk(c)}, (hipStream_t)st, k);
+}
 
 #define HD_SQDIST(fn, M)                                                                               \
     extern "C" int fn##_f32(const void* a, const void* b, void* out, int64_t n, int64_t d, hd_curv c, \

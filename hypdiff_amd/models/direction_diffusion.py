@@ -289,8 +289,40 @@ class diffusion(nn.Module):
 
     def directions(self, u0):
         """[logmap0(u) for u in u0] (:298-300, :342-344) in one launch."""
+        # (cached per centre tensor: a training loop passes the same u0 every step, and a new list of direction tensors
+        # would also miss the sign-table cache below -- four small launches per step)
+        if torch.is_tensor(u0):
+            key = (id(u0), u0._version, u0.data_ptr())
+            hit = getattr(self, "_dir_cache", None)
+            if hit is not None and hit[0] == key and hit[2]() is u0:
+                return hit[1]
         d = self.manifold.logmap0(u0 if torch.is_tensor(u0) else torch.stack(list(u0)), c=1.0)
-        return list(d.unbind(0))
+        out = list(d.unbind(0))
+        if torch.is_tensor(u0):
+            import weakref
+            self._dir_cache = (key, out, weakref.ref(u0))
+        return out
+
+    def _t_frac(self, t):
+        """t / num_timesteps as fp32 (:356-360), correctly rounded like torch's CPU division (the reference's fixtures) and
+        like hd_q_sample_pack_train forms it: torch's GPU division by a Python scalar multiplies by the rounded reciprocal
+        instead, one ulp off for some t.  (fp64 quotient rounded to fp32: exact for integers below 2^24.)"""
+        if torch.is_tensor(t) and not t.is_floating_point():
+            return (t.to(torch.float64) / self.num_timesteps).to(torch.float32)
+        return t / self.num_timesteps
+
+    def _centres64(self, u0):
+        """the centres as one contiguous fp64 (K, D) tensor, cached per centre tensor like the directions"""
+        if torch.is_tensor(u0):
+            key = (id(u0), u0._version, u0.data_ptr())
+            hit = getattr(self, "_c64_cache", None)
+            if hit is not None and hit[0] == key and hit[2]() is u0:
+                return hit[1]
+        c = (u0 if torch.is_tensor(u0) else torch.stack(list(u0))).to(torch.float64).contiguous()
+        if torch.is_tensor(u0):
+            import weakref
+            self._c64_cache = (key, c, weakref.ref(u0))
+        return c
 
     def tran_direction(self, direction_vector, gaussian_point, labels):
         """:154-163, in place on gaussian_point (one kernel instead of a row loop)"""
@@ -443,8 +475,12 @@ class diffusion(nn.Module):
         (loss.backward() runs hd_gemm_tn_f32 / hd_gemm_f32_ex kernels, hypdiff_amd/autograd.py).
         `t` / `noise` optionally inject the draws."""
         x_in = x
-        x = x.to(torch.float64)
-        fresh = x.data_ptr() != x_in.data_ptr()       # a cast copy of our own: nobody can observe the in-place update
+        fresh = x.dtype != torch.float64              # a cast copy of our own: nobody can observe the in-place update
+        # fp32 rows (the encoder's output) on the restricted path: the logmap at the centres widens them on load
+        # (hd_pb_logmap_at_f32_f64: the same bits as x.double() first), so the fp64 copy of x is never made
+        widen = restrict and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous() and x.shape[0] > 0 and x.is_cuda
+        if not widen:
+            x = x.to(torch.float64)
         b, n = x.shape
         t = torch.randint(0, self.num_timesteps, (b,), device=x.device).long() if t is None else t
         own_noise = noise is not None                 # the caller's tensor: tran_direction flips its signs in place
@@ -452,10 +488,18 @@ class diffusion(nn.Module):
             # The draw enters only x_t, which the denoiser reads as fp32 (:57 `x.float()`), so on the fused path below the
             # Gaussian is drawn in fp32 (fp64 arithmetic on it stays as it is): 41 -> 15 us per step at 15 777 x 512
             fused = self.fuse_prepass and graphset and restrict and b > 0
-            noise = torch.randn(x.shape, dtype=torch.float32 if fused else x.dtype, device=x.device)
+            noise = torch.randn(x.shape, dtype=torch.float32 if fused else torch.float64, device=x.device)
         direction = self.directions(u0)
         if not restrict:
             x_start = self.manifold.logmap0(x, c=1.0)
+        elif widen:
+            centres = self._centres64(u0)
+            lab = ops.labels_dev(labels, x.device)
+            if lab.numel() != b:
+                raise ValueError("forward: %d labels for %d rows" % (lab.numel(), b))
+            x_start = torch.empty(b, n, dtype=torch.float64, device=x.device)
+            ops._lib.call("hd_pb_logmap_at_f32_f64", ops._p(centres), ops._p(lab), centres.shape[0], ops._p(x), ops._p(x_start),
+                          b, n, ops.curv(1.0), ops._stream())
         elif fresh:
             centres = u0 if torch.is_tensor(u0) else torch.stack(list(u0))
             x_start = ops.map_at("hd_pb_logmap_at", centres, ops.labels_dev(labels, x.device), x, 1.0)
@@ -473,9 +517,8 @@ class diffusion(nn.Module):
             ld = (n + 1 + 3) // 4 * 4
             target = torch.empty(b, n, dtype=torch.float32, device=x.device)
             h = torch.empty(b, ld, dtype=torch.float32, device=x.device)
-            tcol = (t / self.num_timesteps).to(torch.float32).contiguous()
             ops._lib.call("hd_q_sample_pack_train", ops._p(x_start), ops._p(m), ops._p(noise),
-                          1 if noise.dtype == torch.float64 else 0, 1 if own_noise else 0, ops._p(t.contiguous()), ops._p(tcol),
+                          1 if noise.dtype == torch.float64 else 0, 1 if own_noise else 0, ops._p(t.contiguous()), None,
                           ops._p(lab), ops._p(signs), signs.shape[0], ops._p(self.sqrt_alphas_cumprod),
                           ops._p(self.minus_alphas_cumprod), self.num_timesteps, ops._p(target), ops._p(h), ld, b, n,
                           float(np.sqrt(self.c)), float(self.prior_horizon), float(self.prior), ops._stream())
@@ -484,7 +527,7 @@ class diffusion(nn.Module):
         xt = self.q_sample(x_start=x_start, t=t, direction=direction, noise=noise, labels=labels, u0=u0,
                            restrict=True)
         if graphset:
-            out = self.mlp(xt, t / self.num_timesteps)
+            out = self.mlp(xt, self._t_frac(t))
         else:
-            out = self.gcn(xt, self.edge(adj) if adj.is_sparse else adj, t / self.num_timesteps)
+            out = self.gcn(xt, self.edge(adj) if adj.is_sparse else adj, self._t_frac(t))
         return hag.mse_loss(out, x_start.to(torch.float32))

@@ -155,6 +155,6 @@ class diffusionset(dd.diffusion):
             x_start = self._logmap_centres(x, labels, u0)
         x_start = self.normalization(x_start)
         xt = self.q_sample(x_start=x_start, t=t, direction=direction, noise=noise, labels=labels, u0=u0, restrict=True)
-        out = self.mlp(xt, t / self.num_timesteps)
+        out = self.mlp(xt, self._t_frac(t))
         target = x_start.to(torch.float32)
         return hag.mse_loss(out.reshape(-1, out.shape[-1]), target.reshape(-1, target.shape[-1]))

@@ -71,6 +71,10 @@ HD_DECL2(hd_pb_logmap_at, const void* centres, const int32_t* labels, int64_t n_
          void* out, int64_t rows, int64_t dim, hd_curv c, void* stream)
 HD_DECL2(hd_pb_expmap_at, const void* centres, const int32_t* labels, int64_t n_centres, const void* u,
          void* out, int64_t rows, int64_t dim, hd_curv c, void* stream)
+/* hd_pb_logmap_at_f64 on fp32 rows x (centres fp64, out fp64): diffusion.forward :350-352 runs on x.double() of the
+ * encoder's fp32 output; the rows are widened on load -- the same bits, without the fp64 copy of x. */
+int hd_pb_logmap_at_f32_f64(const void* centres, const int32_t* labels, int64_t n_centres, const void* x, void* out,
+                            int64_t rows, int64_t dim, hd_curv c, void* stream);
 /* sqdist :25-31 -> out (rows,) */
 HD_DECL2(hd_pb_sqdist, const void* p1, const void* p2, void* out, int64_t rows, int64_t dim, hd_curv c,
          void* stream)
@@ -488,7 +492,8 @@ int hd_q_sample(const void* x0, int x_dtype, void* noise, int noise_dtype, const
                 double sqrt_c, double horizon, double prior, void* stream);
 /* The training forward between the moments and the denoiser in one pass (diffusion.forward :335-363 with graphset):
  * normalization (:145-149) with the given {sum, sumsq, count}, q_sample with restrict (:198-213), and the mlp's
- * cat(x_t.float(), t_col) (:57-58; t_col = t / T as the caller's fp32 tensor).  x fp64 (rows, dim); outputs: x_start as fp32 (the loss target, :362) and the packed
+ * cat(x_t.float(), t_col) (:57-58; t_col = t / T as the caller's fp32 tensor, or null: (float)t / (float)T is then formed
+ * in the kernel, which is what torch's int64 / int true division gives).  x fp64 (rows, dim); outputs: x_start as fp32 (the loss target, :362) and the packed
  * fp32 input rows h (row pitch ldh >= dim + 1, zero padded).  Bit-identical to hd_standardize + hd_q_sample +
  * hd_mlp_pack_input.  noise is sign-flipped in place only when write_noise is set (the caller owns it). */
 int hd_q_sample_pack_train(const void* x, const void* moments3, void* noise, int noise_dtype, int write_noise,
