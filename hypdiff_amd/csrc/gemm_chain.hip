@@ -1,12 +1,15 @@
 // A stack of nn.Linear (+ bias, + exact-erf GELU) layers over MANY rows as ONE persistent launch on the bf16 matrix
 // cores: the mlp denoiser of models/direction_diffusion.py:56-69 (D+1 -> 800 -> 900 -> 800 -> 700 -> D over all
-// latent rows of a sampling step).  Arithmetic, limb images and the K loop are those of csrc/gemm_limbs.hip
-// (fp32-faithful 3-limb split, 6 exact limb products per fp32 product, 128 x 64 tile, 4 wavefronts, one LDS
-// buffer, LDS-DMA staging); what is new is the schedule.
+// latent rows of a sampling step), and the two stacks of its training step (forward with the pre-activations kept;
+// the input-gradient GEMMs, epilogue 3).  Arithmetic, limb images and K order are those of csrc/gemm_limbs.hip
+// (fp32-faithful 3-limb split, 6 exact limb products per fp32 product, 4 wavefronts, one LDS buffer, LDS-DMA
+// staging) -- the results are bit-identical to one launch of it per layer; what is new is the schedule and the tile:
+// 128 x 128 (a wavefront 64 x 64) instead of 128 x 64, because the K loop is bound by the bytes staged per MFMA, not
+// by the MFMAs (measured: see the note above the kernel), with a 128 x 64 form for ragged last column tiles.
 //
 // An MLP is row-parallel: layer l + 1 of a 128-row block needs layer l of THAT row block only.  So instead of five
-// launches, each a whole number of tile rounds on 512 workgroup slots (1612 / 1860 / 1612 / 1364 / 992 tiles: 17 rounds
-// where the work is worth 14.5, and four launch ramps and drains), all 7440 tiles of the chain form one stream of
+// launches, each a whole number of tile rounds on 512 workgroup slots with a ramp and a drain, all tiles of the chain
+// (3968 at 15 777 rows) form one stream of
 // work items (layer, row block, column tile) that the resident workgroups pull from device-side queues.  The only
 // synchronisation is a counter per (layer, row block) that the tiles of a row block raise when their part of the
 // limb image is in memory; a tile of the next layer polls it before it stages its A operand.
@@ -18,10 +21,11 @@
 //     (work stealing: the XCDs do not finish together: 124 row blocks are 15.5 per XCD).
 //   * No deadlock whatever the residency: an item depends only on items EARLIER in its own queue, items are handed
 //     out in queue order, and a workgroup holds at most its current item and the one it pulled ahead.  Layer-major
-//     order puts ~200 items of the same queue between a tile and its consumers (64 run at once per XCD), so the
-//     poll is satisfied the first time in practice.  Every wait is bounded (2 s of wall clock): on a time-out the
+//     order puts ~100 items of the same queue between a tile and its consumers (64 run at once per XCD), so the
+//     poll is satisfied the first time for ~80 % of the tiles; the others resolve their successor after the tile, at
+//     the cost of an un-prefetched first slab.  Every wait is bounded (2 s of wall clock): on a time-out the
 //     fail word is raised, every other wait ends at once, the launch runs to its end and the last workgroup fills
-//     the fp32 output with NaN.
+//     the last layer's outputs with NaN (fp32) / bf16 NaN limbs (image).
 //   * Hand-off (MI355X_MICROARCH.md, "Valid forms"): the limb image is written with 16-byte `sc1` (write-through)
 //     stores -- a lane pair's two 8-byte halves of a chunk are brought into one lane by v_permlane16_swap --
 //     every storing wave waits vmcnt(0), the workgroup meets at a barrier, one lane adds to the counter
