@@ -194,6 +194,11 @@ __device__ __forceinline__ bool dep_ready(const ChainArgs& P, const int* tab, in
 // (one per group): the in-kernel phase probe (-DHD_CHAIN_PHASE_PROBE, tools/probes/chain_stamps.py) has wave 0 spend ~40 %
 // of a slab issuing the pieces, but a wave stalled on a piece inside its MFMA stream only lands the slab later.  Timing
 // experiments (-DHD_CHAIN_EXPERIMENT) put the staging + barrier + fragment-read pipeline alone at ~420 us of the 500.
+#ifndef HD_CHAIN_PRIO
+#define HD_CHAIN_PRIO 0            // s_setprio: 1 = raised while the staging pieces are issued, 2 = during the MFMAs.  Measured
+                                   // 458 / 464 us against 460-463 (tools/probes/chain_ab.py): no effect; neither has a start
+                                   // stagger of a CU's second workgroup (HD_MLP_CHAIN_DELAY_NS 400 / 1000 / 3000: 462 / 466 / 460)
+#endif
 #ifndef HD_CHAIN_EXPERIMENT
 #define HD_CHAIN_EXPERIMENT 0      // timing experiments only (results are wrong): 1 = two staging pieces of nine,
 #endif                             // 2 = 8 MFMAs of 48, 3 = 6 fragment reads of 18
@@ -444,8 +449,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                                                                   __builtin_bit_cast(bf16x8, fa[i][al]), c, 0, 0, 0);
                 if (do_stage) {
                     const int kind_next = more ? kind : tile_kind(nl_, ntn_);
+                    if (HD_CHAIN_PRIO == 1) __builtin_amdgcn_s_setprio(3);
                     HD_STAGE(sa, sw, 0, kind_next)
+                    if (HD_CHAIN_PRIO == 1) __builtin_amdgcn_s_setprio(0);
                 }
+                if (HD_CHAIN_PRIO == 2) __builtin_amdgcn_s_setprio(2);
 #define HD_MMS(J0, J1)                                                                                           \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
             _Pragma("unroll") for (int j = J0; j < J1; ++j) {                                                    \
@@ -456,6 +464,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
             }
                 HD_MMS(0, 2)
                 if (NJ == 4 && !narrow) { HD_MMS(2, NJ) }
+                if (HD_CHAIN_PRIO == 2) __builtin_amdgcn_s_setprio(0);
 #undef HD_MMS
 #undef HD_MM
             }
