@@ -355,9 +355,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
 #else
 #define HD_PH(k)
 #endif
+            // (Measured and not kept: a counted wait -- vmcnt(number of image stores of the last write-out) -- at a tile's
+            // first slab, so that it waits for the slab's data and not for the write-through stores behind it, with the
+            // counter add moved one slab down: 462 against 456-463 us, no difference; the stores have been acknowledged by
+            // the time the write-out's arithmetic is over.)
             for (int t = 0; t < nslab; ++t) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 HD_PH(0)
+#ifdef HD_CHAIN_PHASE_PROBE
+                // slab-by-slab timeline of this workgroup's 4th and 5th tile (steady state): time at which each slab's data
+                // had landed (wave 0)
+                if (P.dbg && tid == 0 && (seq == 3 || seq == 4) && t < 32)
+                    P.dbg[512 * 8 + 512 * 24 * 4 + 512 * 8 + ((size_t)blockIdx.x * 2 + (seq - 3)) * 32 + t] = wall_clock64();
+#endif
                 if (async && t == t_poll + 2 && tid == 0) {    // hand the successor to the other wavefronts
                     nxt_s[0] = curq; nxt_s[1] = p_idx; nxt_s[2] = p_ready; nxt_s[3] = p_l; nxt_s[4] = p_rb; nxt_s[5] = p_tn;
                 }

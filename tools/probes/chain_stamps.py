@@ -22,7 +22,7 @@ for dims, M in (([700, 512], 8192), ([700, 512], 15777), ([513, 800, 900, 800, 7
         arr[i] = ops._lib.HdMlpChainLayer(ops._p(wls[i].buf), ops._p(b), None if last else ops._p(outs[i].buf),
                                           ops._p(c) if last else None, wls[i].rows, wls[i].cols, dims[-1], epi)
     ws = torch.zeros(8192, dtype=torch.int32, device="cuda")
-    dbg = torch.zeros(512 * 8 + 512 * 24 * 4 + 512 * 8, dtype=torch.int64, device="cuda")
+    dbg = torch.zeros(512 * 8 + 512 * 24 * 4 + 512 * 8 + 512 * 2 * 32, dtype=torch.int64, device="cuda")
     st = ops._stream()
     os.environ.pop("HD_MLP_CHAIN_DEBUG_PTR", None)
     for _ in range(5):
@@ -39,7 +39,7 @@ for dims, M in (([700, 512], 8192), ([700, 512], 15777), ([513, 800, 900, 800, 7
     full = dbg.cpu().numpy()
     d = full[:512 * 8].reshape(512, 8)
     tl = full[512 * 8:512 * 8 + 512 * 24 * 4].reshape(512, 24, 4)
-    phases = full[512 * 8 + 512 * 24 * 4:].reshape(512, 8)[:, :6].astype(np.float64) / 100.0 / 60.0   # us per launch (60 launches accumulate)
+    phases = full[512 * 8 + 512 * 24 * 4:512 * 8 + 512 * 24 * 4 + 512 * 8].reshape(512, 8)[:, :6].astype(np.float64) / 100.0 / 60.0   # us per launch (60 launches accumulate)
     t0 = d[:, 0].min()
     us = lambda a: (a - t0) / 100.0
     names = ["entry", "first item ready", "first tile K loop done", "first tile written", "loop left", "exit barrier", "exit atomic done"]
@@ -64,11 +64,23 @@ for dims, M in (([700, 512], 8192), ([700, 512], 15777), ([513, 800, 900, 800, 7
             print(f"  layer {l + 1}: {len(r):5d} tiles, K loop {np.median(r[:, 1]):6.2f} us median ({np.percentile(r[:, 1], 10):.2f}-{np.percentile(r[:, 1], 90):.2f}), "
                   f"write-out {np.median(r[:, 2]):5.2f} ({np.percentile(r[:, 2], 10):.2f}-{np.percentile(r[:, 2], 90):.2f}), gap to next {np.nanmedian(r[:, 3]):5.2f} "
                   f"({np.nanpercentile(r[:, 3], 10):.2f}-{np.nanpercentile(r[:, 3], 90):.2f}); starts {r[:, 4].min():.0f}-{r[:, 4].max():.0f} us")
-    clk = full[512 * 8 + 512 * 24 * 4:].reshape(512, 8)[:, 6:8].astype(np.float64)
+    clk = full[512 * 8 + 512 * 24 * 4:512 * 8 + 512 * 24 * 4 + 512 * 8].reshape(512, 8)[:, 6:8].astype(np.float64)
     if clk[:, 1].sum() > 0:
         ghz = clk[:, 0] / np.maximum(clk[:, 1], 1) * 0.1
         print(f"  core clock inside the K loops (s_memtime against the 100 MHz s_memrealtime): median {np.median(ghz):.3f} GHz "
               f"({ghz.min():.3f}-{ghz.max():.3f})")
+    slabs = full[512 * 8 + 512 * 24 * 4 + 512 * 8:].reshape(1024, 32).astype(np.float64)
+    if slabs.sum() > 0 and len(layers) > 1:
+        # slab-to-slab intervals of the 4th / 5th tile of every workgroup, grouped by the tile's slab count
+        by = {}
+        for row in slabs:
+            n = int((row > 0).sum())
+            if n >= 6:
+                by.setdefault(n, []).append(np.diff(row[:n]) / 100.0)
+        for n in sorted(by):
+            d = np.median(np.array(by[n]), axis=0)
+            print(f"  tiles of {n} slabs ({len(by[n])}): median us between slab tops: first {np.round(d[:4], 2).tolist()} ... middle "
+                  f"{np.round(np.median(d[4:n - 7]), 2) if n > 12 else '-'} ... last {np.round(d[-6:], 2).tolist()}")
     if phases.sum() > 0:
         names = ["wait for the slab's LDS-DMA (vmcnt)", "barrier 1", "18 fragment reads + lgkmcnt(0)", "barrier 2", "staging issue + protocol", "48 MFMAs issued (+ write-out tail of the tile)"]
         tot = phases.sum(1)
