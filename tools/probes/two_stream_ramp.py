@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Per-step duration of the headline (two-stream, pipelined across two batches) arrangement right after 100 one-stream
+steps, as bench.py orders its legs: HIP events on the main stream at every step boundary.  Shows how long the
+arrangement takes to reach its steady state.  tools/probes/two_stream_ramp.py [steps]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 80
+w = bench.build_workload(512, 1000, 1432, "cuda:0")
+with torch.no_grad():
+    for i in range(100):
+        bench.one_step(w, 500 - (i % 400), None, i)
+    torch.cuda.synchronize()
+    w["side_stream"] = torch.cuda.Stream()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    ev[0].record()
+    for i in range(steps):
+        bench.one_step(w, 500 - (i % 400), None, i)
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+d = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+for a in range(0, steps, 10):
+    print(f"steps {a:3d}-{a + 9:3d}: " + " ".join(f"{v:.3f}" for v in d[a:a + 10]), flush=True)
