@@ -411,6 +411,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                 // this slab's staging loads: the value the previous step left in flight is taken over (one move, after
                 // which the compiler has no reason to wait again), the loads go out, and only then does the step run --
                 // under the loads' latency -- and issue its own operation behind them.
+                // (As the code stands the step runs AHEAD of the staging loads, and the slab with the decode is 0.5 us longer
+                // than the others (tools/probes/chain_stamps.py); moving the step behind the loads and the decode behind
+                // the MFMAs measured 0.477 against 0.481 of the peak in the bench step, same box, twice: not kept.)
                 const bool act = async && (t == t_pull || t == t_pull + 1 || t == t_poll || t == t_poll + 1);
                 unsigned got = 0;
                 if (act && tid == 0) asm volatile("v_mov_b32 %0, %1" : "=v"(got) : "v"(pend));
@@ -428,23 +431,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                                                __HIP_MEMORY_SCOPE_AGENT);
                     done_l = -1;
                 }
-                HD_PH(4)
-#define HD_MM(wl, al) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[j][wl]), \
-                                                                  __builtin_bit_cast(bf16x8, fa[i][al]), c, 0, 0, 0);
-                if (do_stage) {
-                    const int kind_next = more ? kind : tile_kind(nl_, ntn_);
-                    if (HD_CHAIN_PRIO == 1) __builtin_amdgcn_s_setprio(3);
-                    HD_STAGE(sa, sw, 0, kind_next)
-                    if (HD_CHAIN_PRIO == 1) __builtin_amdgcn_s_setprio(0);
-                }
-                // thread 0's protocol step: its memory operation goes out BEHIND this slab's staging loads
                 if (act && tid == 0) {
                     unsigned* addr = nullptr;
                     unsigned inc = 0;
                     if (t == t_pull) {
                         if (tried < 8 && qlen(curq) > 0) { addr = ws + curq * 32; inc = 1; p_state = 1; }
                     } else if (t == t_pull + 1) {
-                        // (the decode -- integer divisions, no memory operation -- runs behind the MFMAs below)
+                        if (p_state == 1 && got < (unsigned)qlen(curq)) {
+                            p_idx = (int)got;
+                            decode(tab, P.n_layers, tiles_m, curq, p_idx, p_l, p_rb, p_tn);
+                            p_state = 2;
+                        }
                     } else if (t == t_poll) {
                         if (p_state == 2) {
                             if (p_l == 0) p_ready = 1;
@@ -460,6 +457,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                     }
                     if (addr) pend = __hip_atomic_fetch_add(addr, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                HD_PH(4)
+#define HD_MM(wl, al) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fw[j][wl]), \
+                                                                  __builtin_bit_cast(bf16x8, fa[i][al]), c, 0, 0, 0);
+                if (do_stage) {
+                    const int kind_next = more ? kind : tile_kind(nl_, ntn_);
+                    if (HD_CHAIN_PRIO == 1) __builtin_amdgcn_s_setprio(3);
+                    HD_STAGE(sa, sw, 0, kind_next)
+                    if (HD_CHAIN_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+                }
                 if (HD_CHAIN_PRIO == 2) __builtin_amdgcn_s_setprio(2);
 #define HD_MMS(J0, J1)                                                                                           \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
@@ -472,11 +478,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                 HD_MMS(0, 2)
                 if (NJ == 4 && !narrow) { HD_MMS(2, NJ) }
                 if (HD_CHAIN_PRIO == 2) __builtin_amdgcn_s_setprio(0);
-                if (async && t == t_pull + 1 && tid == 0 && p_state == 1 && got < (unsigned)qlen(curq)) {
-                    p_idx = (int)got;                           // the pulled item: which tile it is (under the MFMAs' execution)
-                    decode(tab, P.n_layers, tiles_m, curq, p_idx, p_l, p_rb, p_tn);
-                    p_state = 2;
-                }
 #undef HD_MMS
 #undef HD_MM
             }

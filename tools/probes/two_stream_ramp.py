@@ -12,11 +12,16 @@ import bench  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 80
 w = bench.build_workload(512, 1000, 1432, "cuda:0")
+early = len(sys.argv) > 2 and sys.argv[2] == "early"      # create the side stream (and touch it) before the one-stream steps
+if early:
+    side0 = torch.cuda.Stream()
+    with torch.cuda.stream(side0):
+        torch.zeros(1024, device="cuda:0").add_(1)
 with torch.no_grad():
     for i in range(100):
         bench.one_step(w, 500 - (i % 400), None, i)
     torch.cuda.synchronize()
-    w["side_stream"] = torch.cuda.Stream()
+    w["side_stream"] = side0 if early else torch.cuda.Stream()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     ev[0].record()
     for i in range(steps):
