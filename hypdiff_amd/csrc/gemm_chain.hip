@@ -194,6 +194,11 @@ __device__ __forceinline__ bool dep_ready(const ChainArgs& P, const int* tab, in
 // (one per group): the in-kernel phase probe (-DHD_CHAIN_PHASE_PROBE, tools/probes/chain_stamps.py) has wave 0 spend ~40 %
 // of a slab issuing the pieces, but a wave stalled on a piece inside its MFMA stream only lands the slab later.  Timing
 // experiments (-DHD_CHAIN_EXPERIMENT) put the staging + barrier + fragment-read pipeline alone at ~420 us of the 500.
+#ifndef HD_CHAIN_WO
+#define HD_CHAIN_WO 2              // write-out: 0 = bias loads per column pair, scalar GELU; 1 = a tile's bias loads in one batch;
+                                   // 2 = 1 + GELU on the packed fp32 pipe (same bits).  Same-box A/B in the bench step
+                                   // (tools/probes/bench_ab.sh, twice): 183.6 / 184.1 -> 184.3 / 185.1 -> 185.5 / 184.9 TF
+#endif
 #ifndef HD_CHAIN_PRIO
 #define HD_CHAIN_PRIO 0            // s_setprio: 1 = raised while the staging pieces are issued, 2 = during the MFMAs.  Measured
                                    // 458 / 464 us against 460-463 (tools/probes/chain_ab.py): no effect; neither has a start
@@ -509,6 +514,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                 // this lane's chunk after the pair swap: even 16-lane rows keep the even accumulator of a pair (chunk
                 // kc = kq / 2), odd rows the odd one (kc = 2 + kq / 2)
                 const int kc_mine = (kq & 1) * 2 + (kq >> 1);
+                // HD_CHAIN_WO >= 1: the tile's bias values of this lane, all loads in flight at once
+                float bq4[NJ][4];
+                if (HD_CHAIN_WO >= 1) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int n = n0 + j * 16 + 4 * kq + e;
+                            bq4[j][e] = (bias && n < N && !(narrow && j >= 2)) ? bias[n] : 0.f;
+                        }
+                }
 #pragma unroll
                 for (int jp = 0; jp < NJ / 2; ++jp) {
                     if (jp && narrow) continue;
@@ -523,7 +539,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int n = nq + j * 16 + 4 * kq + e;
-                            bq[j][e] = (bias && n < N) ? bias[n] : 0.f;
+                            if (HD_CHAIN_WO >= 1) bq[j][e] = bq4[2 * jp + j][e];
+                            else bq[j][e] = (bias && n < N) ? bias[n] : 0.f;
                         }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -564,7 +581,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                                 for (int e = 0; e < 4; ++e) x[e] *= gelu_erf_grad(r[e]);
                             } else if (epi == 1) {
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) x[e] = gelu_erfc(x[e]);
+                                for (int e = 0; e < 4; e += 2) {
+                                    if (HD_CHAIN_WO >= 2) {
+                                        const hd_f32x2 g = gelu_erfc2(hd_f32x2{x[e], x[e + 1]});
+                                        x[e] = g.x; x[e + 1] = g.y;
+                                    } else {
+                                        x[e] = gelu_erfc(x[e]); x[e + 1] = gelu_erfc(x[e + 1]);
+                                    }
+                                }
                             }
                             // columns past N are the zero padding of the next layer's K; rows past M are written as zeros
 #pragma unroll

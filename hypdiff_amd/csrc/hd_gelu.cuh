@@ -77,6 +77,24 @@ __device__ __forceinline__ float gelu_erfc(float x) {
     const float e = __builtin_amdgcn_exp2f(r * t);                       // erfc(|a|)
     return x * (x >= 0.f ? fmaf(-0.5f, e, 1.0f) : 0.5f * e);
 }
+// gelu_erfc on two values at a time (v_pk_mul_f32 / v_pk_fma_f32: the same operations per element in the same order, so
+// the same bits; exp2 and the select stay per element)
+__device__ __forceinline__ hd_f32x2 gelu_erfc2(hd_f32x2 x) {
+    const hd_f32x2 a = x * 0.70710678118654752440f;
+    const hd_f32x2 t = {fabsf(a.x), fabsf(a.y)};
+    auto fma2 = [](hd_f32x2 p, hd_f32x2 q, float c) { return __builtin_elementwise_fma(p, q, hd_f32x2{c, c}); };
+    hd_f32x2 r = {-4.535861479e-05f, -4.535861479e-05f};
+    r = fma2(r, t, 4.455077501e-04f);
+    r = fma2(r, t, -1.489441880e-03f);
+    r = fma2(r, t, -7.746293751e-04f);
+    r = fma2(r, t, 2.825368093e-02f);
+    r = fma2(r, t, -1.484816150e-01f);
+    r = fma2(r, t, -9.184163933e-01f);
+    r = fma2(r, t, -1.627908593e+00f);
+    const hd_f32x2 rt = r * t;
+    const float e0 = __builtin_amdgcn_exp2f(rt.x), e1 = __builtin_amdgcn_exp2f(rt.y);
+    return hd_f32x2{x.x * (x.x >= 0.f ? fmaf(-0.5f, e0, 1.0f) : 0.5f * e0), x.y * (x.y >= 0.f ? fmaf(-0.5f, e1, 1.0f) : 0.5f * e1)};
+}
 // d/dx of the exact-erf GELU: Phi(x) + x * phi(x).  Phi from the same single-polynomial erfc as gelu_erfc (Phi(x) =
 // erfc(-x / sqrt 2) / 2: no 1 + erf cancellation on the negative side), phi as one exp2: ~18 VALU ops instead of ~40 --
 // the backward write-outs (epilogue 3) are VALU-bound on it.  Max abs error against fp64 over [-9, 9]: 1.3e-7 (the
