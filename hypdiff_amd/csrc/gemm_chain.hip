@@ -734,14 +734,15 @@ extern "C" int hd_mlp_chain_limbs_f32(const void* A0, int64_t rows, const hd_mlp
     P.n_layers = n_layers;
     P.M = (int)rows;
     P.tiles_m = (int)((rows + 127) / 128);
-    struct Knobs { int n_cu, delay_ns, flags, reload, per_cu, tail; };
+    struct Knobs { int n_cu, delay_ns, flags, reload, per_cu, tail, grid; };
     static Knobs knobs = [] {
-        Knobs k{256, 0, 0, 0, 2, 0};
+        Knobs k{256, 0, 0, 0, 2, 0, 0};
         if (const char* e = getenv("HD_MLP_CHAIN_PER_CU")) k.per_cu = atoi(e);
         if (const char* e = getenv("HD_MLP_CHAIN_DELAY_NS")) k.delay_ns = atoi(e);
         if (const char* e = getenv("HD_MLP_CHAIN_FLAGS")) k.flags = atoi(e);
         if (const char* e = getenv("HD_GEMM_TUNE_RELOAD")) k.reload = atoi(e);
         if (const char* e = getenv("HD_MLP_CHAIN_TAIL")) k.tail = atoi(e);
+        if (const char* e = getenv("HD_MLP_CHAIN_GRID")) k.grid = atoi(e);
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -810,7 +811,11 @@ extern "C" int hd_mlp_chain_limbs_f32(const void* A0, int64_t rows, const hd_mlp
     const int64_t total = items;
     // The kernel's registers (252) admit two workgroups per CU, its LDS (48 KB) three; unused dynamic LDS pads the
     // footprint so that exactly `per_cu` workgroups fit a CU (160 KB) and the grid fills the chip evenly.
-    int64_t grid = grid_full;
+    // HD_MLP_CHAIN_GRID: fewer workgroups than fill the chip (a multiple of 8), leaving slots to kernels of other streams.
+    // In the bench's pipelined two-stream step (same box, tools/probes/bench_ab.sh): 512 / 496 / 480 / 448 / 384 workgroups
+    // -> 0.637-0.643 / 0.653 / 0.631 / 0.629 / 0.634 ms per step while the chain itself goes 194 -> 192 / 189 / 181 / 168 TF:
+    // a 1-2 % gain of the pipelined step for a 3-7 % loss of the kernel and of the one-stream step, so the default stays full.
+    int64_t grid = knobs.grid >= 8 && knobs.grid < grid_full ? knobs.grid / 8 * 8 : grid_full;
     if (grid > total) grid = total;
     const size_t static_lds = CH_BUF * 16 + 64;
     const size_t want = per_cu == 2 ? 56 * 1024 : 100 * 1024;
