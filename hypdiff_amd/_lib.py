@@ -40,6 +40,12 @@ class HdAdamJob(ctypes.Structure):
     _fields_ = [("param", c_void_p), ("offset", c_int64), ("count", c_int64)]
 
 
+class HdTnJob(ctypes.Structure):
+    """struct hd_tn_job of include/hypdiff.h"""
+    _fields_ = [("a_img", c_void_p), ("b_img", c_void_p), ("c", c_void_p), ("colsum_a", c_void_p), ("P", c_int64),
+                ("Q", c_int64), ("ldc", c_int64)]
+
+
 class HdTransposeJob(ctypes.Structure):
     """struct hd_transpose_job of include/hypdiff.h"""
     _fields_ = [("inp", c_void_p), ("out", c_void_p), ("rows", c_int64), ("cols", c_int64), ("ld_in", c_int64),
@@ -60,6 +66,7 @@ SIZE_QUERIES = {
     "hd_gemm_tn_workspace_floats": [I64, I64, I64],
     "hd_gemm_splitk_workspace_floats": [I64, I64, I64],
     "hd_gemm_tn_bf16x3_workspace_floats": [I64, I64, I64],
+    "hd_gemm_tn_limbs_multi_workspace_floats": [I64, POINTER(HdTnJob), c_int],
     "hd_colsum_workspace_floats": [I64, I64],
     "hd_mse_workspace_doubles": [],
     "hd_hkm_workspace_doubles": [I64, I64, I64],
@@ -135,6 +142,7 @@ SIGNATURES = {
     "hd_gemm_tn_f32": [P, P, P, I64, I64, I64, I64, I64, I64, P, P],
     "hd_gemm_tn_bf16x3_f32": [P, P, P, P, I64, I64, I64, I64, I64, I64, P, P],
     "hd_gemm_tn_limbs_f32": [P, P, P, P, I64, I64, I64, I64, P, P],
+    "hd_gemm_tn_limbs_multi_f32": [I64, POINTER(HdTnJob), c_int, P, P],
     "hd_transpose_f32": [P, P, I64, I64, I64, I64, P],
     "hd_transpose_multi_f32": [POINTER(HdTransposeJob), c_int, P],
     "hd_adam_step_f32": [POINTER(HdAdamJob), c_int, P, P, P, c_double, c_double, c_double, c_double, I64, P, P],

@@ -15,6 +15,8 @@ ddpm.py:71-85).  Here one Function covers a whole Linear(+GELU)(+residual) stack
 
 PyTorch owns memory, the autograd graph and RNG (and the optimizer unless dist.BucketAdam is used); nothing else.
 """
+import os
+
 import torch
 
 from . import _lib, ops
@@ -26,6 +28,8 @@ GELU, RES, LIN = 1, 2, 0        # layer kinds = epilogue codes of hd_gemm_f32
 # dW / db straight into the bucket and reports it, so the bucket's chunk can start its all-reduce while
 # the layers below are still in their GEMMs.  Parameters are assumed to enter the graph once per step.
 GRAD_SINK = None
+# the weight gradients of a chained backward pass as one launch (hd_gemm_tn_limbs_multi_f32); False: one launch per layer
+TN_MULTI = os.environ.get("HD_TN_MULTI", "1") != "0"
 
 
 def _ws(n, dtype, device):
@@ -142,6 +146,50 @@ def gemm_tn_limbs(a_img, b_img, out=None, colsum_out=None):
         colsum_out.copy_(cs[: colsum_out.numel()])
         cs = colsum_out
     return out, cs
+
+
+def gemm_tn_limbs_multi(jobs):
+    """[(a^T @ b, colsum(a)) for (a_img, b_img, out, colsum_out) in jobs] in ONE launch (hd_gemm_tn_limbs_multi_f32):
+    products over the same rows that do not depend on each other -- the weight gradients of a backward pass.  Every
+    product is cut and summed exactly as gemm_tn_limbs cuts and sums it (bit-identical).  out / colsum_out: fp32
+    tensors of the padded shapes (P, Q) / (P,), contiguous and 16-byte aligned, or None (allocated here)."""
+    if not jobs:
+        return []
+    R = jobs[0][0].rows
+    dev = jobs[0][0].buf.device
+    res = []
+    arr = (_lib.HdTnJob * len(jobs))()
+    flops = nbytes = 0.0
+    for i, (a_img, b_img, out, cs) in enumerate(jobs):
+        assert a_img.rows == R and b_img.rows == R and a_img.fmt == b_img.fmt == "bf16x3"
+        P, Q = (a_img.cols + 3) // 4 * 4, (b_img.cols + 3) // 4 * 4
+        fits = out is not None and out.data_ptr() % 16 == 0 and out.is_contiguous() and tuple(out.shape) == (P, Q)
+        o = out if fits else torch.empty(P, Q, dtype=torch.float32, device=dev)
+        cfits = cs is not None and cs.data_ptr() % 16 == 0 and cs.is_contiguous() and cs.numel() == P
+        c = cs if cfits else torch.empty(P, dtype=torch.float32, device=dev)
+        arr[i] = _lib.HdTnJob(ops._p(a_img.buf), ops._p(b_img.buf), ops._p(o), ops._p(c), P, Q, o.stride(0))
+        res.append((o, c, out, cs, fits, cfits))
+        flops += 2.0 * R * P * Q
+        nbytes += 6.0 * (R * P + R * Q) + 4.0 * P * Q
+    ws = _ws(_lib.load().hd_gemm_tn_limbs_multi_workspace_floats(R, arr, len(jobs)), torch.float32, dev)
+    ev = ops.GEMM_EVENTS
+    if ev is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.call("hd_gemm_tn_limbs_multi_f32", R, arr, len(jobs), ops._p(ws), ops._stream())
+    if ev is not None:
+        e1.record()
+        ev.append((e0, e1, flops, nbytes))
+    outs = []
+    for o, c, out, cs, fits, cfits in res:
+        if out is not None and not fits:
+            out.copy_(o[: out.shape[0], : out.shape[1]])
+            o = out
+        if cs is not None and not cfits:
+            cs.copy_(c[: cs.numel()])
+            c = cs
+        outs.append((o, c))
+    return outs
 
 
 def transpose(w):
@@ -363,6 +411,32 @@ class LinearStack(torch.autograd.Function):
             dz_imgs = {L - 1: dz_img}
             for k, l in enumerate(range(L - 1, 0, -1)):
                 dz_imgs[l - 1] = outs[k][0]
+        if dz_imgs is not None and TN_MULTI:
+            # every dz image exists: the L weight gradients are independent products over the same rows -- one launch
+            # (two when a gradient bucket has all-reduces to overlap: the top layers' chunks go on the wire while the
+            # lower layers' gradients are still being multiplied)
+            order = list(range(L - 1, -1, -1))
+            split = sink is not None and sink.wants_overlap() and L >= 4
+            for grp in ([order[:2], order[2:]] if split else [order]):
+                jobs, views = [], []
+                for l in grp:
+                    wp, bp = ctx.params[2 * l], ctx.params[2 * l + 1]
+                    wv = sink.view_for(wp) if sink is not None else None
+                    bv = sink.view_for(bp) if sink is not None else None
+                    if wv is None or bv is None:
+                        wv = bv = None
+                    jobs.append((dz_imgs[l], ctx.x_imgs[l], wv, bv))
+                    views.append(wv is not None)
+                for l, (dw, db), in_bucket in zip(grp, gemm_tn_limbs_multi(jobs), views):
+                    if in_bucket:
+                        sink.delivered(ctx.params[2 * l + 1])
+                        sink.delivered(ctx.params[2 * l])
+                    else:
+                        shp = ctx.wshapes[l]
+                        grads[2 * l] = dw if tuple(dw.shape) == shp else dw[: shp[0], : shp[1]].contiguous()
+                        grads[2 * l + 1] = db if db.numel() == shp[0] else db[: shp[0]].contiguous()
+            ctx.x_imgs = ctx.wt_imgs = None
+            return (None, None, *grads)
         for l in range(L - 1, -1, -1):
             if dz_imgs is not None:
                 dz_img = dz_imgs[l]

@@ -152,43 +152,56 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16x3(const float* __restrict__ 
 // one row -- the transpose is gfx950's ds_read_b64_tr_b16: a slab of 32 rows goes to LDS by LDS-DMA as 48 sub-tiles
 // [32 rows][16 columns] of 1 KB (operand, 32-column slab, limb, column half), and a 16-lane group reads a 4-row x
 // 16-column block of one and receives it column-major, i.e. 4 consecutive k of its own column: two reads make one
-// v_mfma_f32_16x16x32_bf16 operand.  Rows sit in the sub-tile in the order (bit 2 <-> bit 3 swapped), so that the 32
-// lanes of a half-wavefront (rows 8g..8g+3 of two groups, 32 bytes each) cover one 256-byte bank row: conflict-free.
+// v_mfma_f32_16x16x32_bf16 operand.  A sub-tile holds the chunk of (row r, 8-column half h) at position
+// 32 h + (r ^ 4 h): lanes 0..31 of the LDS-DMA fetch one 512-byte run of the image and lanes 32..63 another (whole
+// 128-byte lines), and the 32 lanes of a half-wavefront of the transposing read (rows 8g..8g+3 of two groups, both
+// halves, 8 bytes each) cover one 256-byte bank row: conflict-free.  (Round 3: the earlier [row][half] order, whose
+// neighbouring lanes fetched from two runs 2 KB apart, measured the same to the microsecond; so did every slab served
+// from the L2 (a timing build that re-read two slabs) and a start-up delay of 0.3-3 us for the second workgroup of a CU:
+// the kernel runs 1.9-2.1 us per slab like the forward chain, and what separated five launches from that was ~22 us
+// of fixed cost per launch -- ramp, 33 MB of partial tiles, the reduction launch -- hence the one-launch form below.)
 // The pad rows of the last 128-row block must be ZERO in both images (hd_limb_pack*_f32 and the limb GEMM's write-out
 // zero them).  The bias gradient is three extra multiplies per 16 columns with an all-ones operand in the first tile column.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 struct Frag8 { s16x4 lo, hi; };
 
-__device__ __forceinline__ lbf16x8 tr_frag(const __attribute__((address_space(3))) char* base, int imm) {
+// rows 8 kq .. + 3 of the sub-tile at `lo + imm`, rows 8 kq + 4 .. + 7 at `hi + imm`
+__device__ __forceinline__ lbf16x8 tr_frag(const __attribute__((address_space(3))) char* lo,
+                                           const __attribute__((address_space(3))) char* hi, int imm) {
     Frag8 f;
     f.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        reinterpret_cast<__attribute__((address_space(3))) s16x4*>(const_cast<__attribute__((address_space(3))) char*>(base + imm)));
+        reinterpret_cast<__attribute__((address_space(3))) s16x4*>(const_cast<__attribute__((address_space(3))) char*>(lo + imm)));
     f.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        reinterpret_cast<__attribute__((address_space(3))) s16x4*>(const_cast<__attribute__((address_space(3))) char*>(base + imm + 256)));
+        reinterpret_cast<__attribute__((address_space(3))) s16x4*>(const_cast<__attribute__((address_space(3))) char*>(hi + imm)));
     return __builtin_bit_cast(lbf16x8, f);
 }
 
-__global__ __launch_bounds__(256) void gemm_tn_img(const uint4* __restrict__ Aimg, const uint4* __restrict__ Bimg,
-                                                   float* __restrict__ out, int R, int P, int Q, int ldo, int chunk,
-                                                   int tiles_q, int tiles, int total, size_t slice_stride,
-                                                   float* __restrict__ cs_out) {
-    __shared__ __attribute__((aligned(1024))) uint4 lds[48 * 64];  // [operand][slab][limb][column half][32 rows x 16 columns]
+// one product C = A^T B cut into `tiles` 128 x 128 tiles and row slices of `chunk` rows: work item vid = slice * tiles + tile
+struct TnJob {
+    const uint4* Aimg;
+    const uint4* Bimg;
+    float* out;               // C itself (one slice) or the workspace of partial tiles
+    float* cs_out;            // column sums of A (per slice), or null
+    int R, P, Q, ldo, chunk, tiles_q, tiles, total;
+    size_t slice_stride;
+};
+
+// work item `vid` of job J by this workgroup; `lds` = 48 KB, free on entry (every wavefront holds no fragment of it) and on exit
+__device__ __forceinline__ void tn_img_item(const TnJob& J, int vid, uint4* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per_xcd = (gridDim.x + 7) >> 3;
-    const int vid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (vid >= total) return;                                     // uniform
-    const int tile = vid % tiles, slice = vid / tiles;
-    const int tp = tile / tiles_q, tq = tile - tp * tiles_q;
+    const int R = J.R, P = J.P, Q = J.Q, ldo = J.ldo;
+    const int tile = vid % J.tiles, slice = vid / J.tiles;
+    const int tp = tile / J.tiles_q, tq = tile - tp * J.tiles_q;
     const int p0 = tp * TP, q0 = tq * TQ;
-    const int r_begin = slice * chunk, r_end = r_begin + chunk < R ? r_begin + chunk : R;
+    const int r_begin = slice * J.chunk, r_end = r_begin + J.chunk < R ? r_begin + J.chunk : R;
     const int nslab = (r_end - r_begin + TR - 1) / TR;
     // staging: wavefront w brings sub-tiles 12 w .. 12 w + 11 (waves 0, 1: A; 2, 3: B); lane L fetches the chunk of column
-    // half L & 1, row swap23(L >> 1) of the slab, into position L of the sub-tile
+    // half L >> 5, row (L & 31) ^ 4 (L >> 5) of the slab, into position L of the sub-tile
     const int op = wave >> 1;
-    const uint4* img = op ? Bimg : Aimg;
+    const uint4* img = op ? J.Bimg : J.Aimg;
     const int nsl_img = ((op ? Q : P) + 31) >> 5, s0 = (op ? q0 : p0) >> 5;
-    const int slot = lane >> 1;
-    const int row_l = (slot & 19) | ((slot & 4) << 1) | ((slot & 8) >> 1);
+    const int half_l = lane >> 5;
+    const int row_l = (lane & 31) ^ (4 * half_l);
     unsigned lane_off[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
@@ -196,7 +209,7 @@ __global__ __launch_bounds__(256) void gemm_tn_img(const uint4* __restrict__ Aim
         const int sl = rem / 6, l = (rem % 6) >> 1, kp = rem & 1;
         int sg = s0 + sl;
         sg = sg < nsl_img ? sg : nsl_img - 1;                    // beyond the image: any valid slab (columns never written out)
-        lane_off[k] = (unsigned)(sg * 1536 + l * 512 + (2 * kp + (lane & 1)) * 128 + row_l);
+        lane_off[k] = (unsigned)(sg * 1536 + l * 512 + (2 * kp + half_l) * 128 + row_l);
     }
     auto stage = [&](int t) {
         const int r = r_begin + t * TR;
@@ -206,10 +219,16 @@ __global__ __launch_bounds__(256) void gemm_tn_img(const uint4* __restrict__ Aim
     };
     const int r16 = lane & 15, kq = lane >> 4;
     const int wr = wave >> 1, wc = wave & 1;
-    const int lane_base = (((kq >> 1) * 16 + (kq & 1) * 4 + (r16 >> 2)) * 32) + 8 * (r16 & 3);
+    // lane (rho = r16 >> 2, gamma = r16 & 3) reads columns 4 gamma .. + 3 of row 8 kq + rho (then + 4): half h = gamma >> 1,
+    // position 32 h + (row ^ 4 h), 8 (gamma & 1) bytes into the chunk
+    const int h_r = (r16 & 3) >> 1;
+    const int lane_lo = 512 * h_r + 16 * ((8 * kq + (r16 >> 2)) ^ (4 * h_r)) + 8 * (r16 & 1);
+    const int lane_hi = 512 * h_r + 16 * ((8 * kq + (r16 >> 2) + 4) ^ (4 * h_r)) + 8 * (r16 & 1);
     const auto* lbase = (const __attribute__((address_space(3))) char*)lds;
-    const auto* a_base = lbase + lane_base + wr * 12288;
-    const auto* b_base = lbase + lane_base + 24576 + wc * 12288;
+    const auto* a_lo = lbase + lane_lo + wr * 12288;
+    const auto* a_hi = lbase + lane_hi + wr * 12288;
+    const auto* b_lo = lbase + lane_lo + 24576 + wc * 12288;
+    const auto* b_hi = lbase + lane_hi + 24576 + wc * 12288;
     lf32x4 acc[4][4], csa[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -217,7 +236,7 @@ __global__ __launch_bounds__(256) void gemm_tn_img(const uint4* __restrict__ Aim
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = lf32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const bool do_cs = cs_out != nullptr && tq == 0 && wc == 0;  // uniform over the wavefront
+    const bool do_cs = J.cs_out != nullptr && tq == 0 && wc == 0;  // uniform over the wavefront
     const lbf16x8 ones = __builtin_bit_cast(lbf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
     if (nslab > 0) stage(0);
     for (int t = 0; t < nslab; ++t) {
@@ -229,8 +248,8 @@ __global__ __launch_bounds__(256) void gemm_tn_img(const uint4* __restrict__ Aim
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int imm = ((i >> 1) * 6 + l * 2 + (i & 1)) * 1024;
-                fa[i][l] = tr_frag(a_base, imm);
-                fb[i][l] = tr_frag(b_base, imm);
+                fa[i][l] = tr_frag(a_lo, a_hi, imm);
+                fb[i][l] = tr_frag(b_lo, b_hi, imm);
             }
         __syncthreads();                                          // every wavefront holds its fragments: buffer free
         if (t + 1 < nslab) stage(t + 1);                          // in flight during the multiplies
@@ -257,10 +276,10 @@ __global__ __launch_bounds__(256) void gemm_tn_img(const uint4* __restrict__ Aim
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = p0 + wr * 64 + i * 16 + r16;
-            if (p < P) cs_out[(size_t)slice * P + p] = csa[i][0];
+            if (p < P) J.cs_out[(size_t)slice * P + p] = csa[i][0];
         }
     }
-    float* o = out + (size_t)slice * slice_stride;
+    float* o = J.out + (size_t)slice * J.slice_stride;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int p = p0 + wr * 64 + i * 16 + r16;
@@ -271,6 +290,38 @@ __global__ __launch_bounds__(256) void gemm_tn_img(const uint4* __restrict__ Aim
             if (q < Q)
                 *reinterpret_cast<float4*>(o + (size_t)p * ldo + q) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_img(const TnJob J) {
+    __shared__ __attribute__((aligned(1024))) uint4 lds[48 * 64];  // [operand][slab][limb][column half][32 rows x 16 columns]
+    // workgroup b runs on XCD b % 8: every XCD a contiguous run of (slice, tile) pairs (shared rows meet in one L2)
+    const int per_xcd = (gridDim.x + 7) >> 3;
+    const int vid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (vid >= J.total) return;                                   // uniform
+    tn_img_item(J, vid, lds);
+}
+
+// Several products that share the contraction rows (the five weight gradients of the denoiser's backward pass: they
+// are independent of each other) in ONE launch of resident workgroups: workgroup b takes, job after job, the item
+// vid_j = (v(b) - rot_j) mod grid of job j when the job has that many items, v(b) as above.  Jobs are cut exactly as
+// hd_gemm_tn_limbs_f32 cuts them (same slices, same slab order, same reduction order: bit-identical results); rot_j
+// is the running sum of the item counts, so the workgroups a job leaves idle are the first of the next one.  No
+// workgroup waits for another: a job's items start as their workgroups finish the previous job's.
+constexpr int kMaxTnJobs = 8;
+struct TnMulti {
+    TnJob job[kMaxTnJobs];
+    int rot[kMaxTnJobs];
+    int n;
+};
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_tn_img_multi(const TnMulti M) {
+    __shared__ __attribute__((aligned(1024))) uint4 lds[48 * 64];
+    const int grid = (int)gridDim.x, per_xcd = grid >> 3;        // the host launches a multiple of 8 workgroups
+    const int v = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    for (int j = 0; j < M.n; ++j) {
+        int vid = v - M.rot[j];
+        vid += vid < 0 ? grid : 0;
+        if (vid < M.job[j].total) tn_img_item(M.job[j], vid, lds);
     }
 }
 
@@ -287,6 +338,36 @@ __global__ __launch_bounds__(256) void tn_reduce(const float* __restrict__ ws, i
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
         *reinterpret_cast<float4*>(second ? out2 + (i - count) : out + i) = s;
+    }
+}
+
+// the same reduction for several products in one launch: blockIdx.y = job
+struct TnReduceJob {
+    const float* ws;
+    const float* ws2;
+    float* out;
+    float* out2;
+    size_t count, count2;
+    int nsl;
+};
+struct TnReduceJobs {
+    TnReduceJob job[kMaxTnJobs];
+    int n;
+};
+__global__ __launch_bounds__(256) void tn_reduce_multi(const TnReduceJobs J) {
+    const TnReduceJob& r = J.job[blockIdx.y];
+    const size_t count = r.count, count2 = r.count2;
+    const int nsl = r.nsl;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < count + count2; i += (size_t)gridDim.x * 256 * 4) {
+        const bool second = i >= count;
+        const float* src = second ? r.ws2 + (i - count) : r.ws + i;
+        const size_t stride = second ? count2 : count;
+        float4 s = *reinterpret_cast<const float4*>(src);
+        for (int k = 1; k < nsl; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)k * stride);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(second ? r.out2 + (i - count) : r.out + i) = s;
     }
 }
 
@@ -346,45 +427,130 @@ extern "C" int hd_gemm_tn_bf16x3_f32(const void* A, const void* B, void* C, void
     return check_launch("hd_gemm_tn_bf16x3_f32");
 }
 
-extern "C" int hd_gemm_tn_limbs_f32(const void* Aimg, const void* Bimg, void* C, void* colsum_a, int64_t R, int64_t P,
-                                    int64_t Q, int64_t ldc, void* workspace, void* st) {
-    HD_REQUIRE(R >= 0 && P >= 1 && Q >= 1, "hd_gemm_tn_limbs_f32: bad shape R=%lld P=%lld Q=%lld", (long long)R, (long long)P,
-               (long long)Q);
-    HD_REQUIRE(C && (R == 0 || (Aimg && Bimg)), "hd_gemm_tn_limbs_f32: null pointer");
-    HD_REQUIRE(R < (1LL << 31) && P < (1LL << 24) && Q < (1LL << 24), "hd_gemm_tn_limbs_f32: size exceeds the index range");
+// plan of one image product: how hd_gemm_tn_limbs_f32 cuts it (tiles, slices), where its partial tiles go
+struct TnPlan {
+    TnJob job;
+    int nsl;
+    size_t count, count2;     // P * Q, P (or 0 without a bias gradient)
+    float *ws, *cs_ws, *C, *cs;
+};
+static int tn_plan(const char* who, const void* Aimg, const void* Bimg, void* C, void* colsum_a, int64_t R, int64_t P,
+                   int64_t Q, int64_t ldc, float* workspace, TnPlan& pl) {
+    HD_REQUIRE(P >= 1 && Q >= 1, "%s: bad shape R=%lld P=%lld Q=%lld", who, (long long)R, (long long)P, (long long)Q);
+    HD_REQUIRE(C && Aimg && Bimg, "%s: null pointer", who);
+    HD_REQUIRE(P < (1LL << 24) && Q < (1LL << 24), "%s: size exceeds the index range", who);
     HD_REQUIRE(P % 4 == 0 && Q % 4 == 0 && ldc % 4 == 0 && ldc >= Q && is_aligned16(C) && is_aligned16(Aimg) && is_aligned16(Bimg),
-               "hd_gemm_tn_limbs_f32: P, Q, ldc must be multiples of 4 and the images and C 16-byte aligned");
-    HD_REQUIRE(!colsum_a || is_aligned16(colsum_a), "hd_gemm_tn_limbs_f32: colsum_a must be 16-byte aligned");
-    hipStream_t s = (hipStream_t)st;
-    if (R == 0) {
-        HD_REQUIRE(ldc == Q, "hd_gemm_tn_limbs_f32: empty reduction needs a contiguous output");
-        if (hipMemsetAsync(C, 0, (size_t)P * Q * sizeof(float), s) != hipSuccess ||
-            (colsum_a && hipMemsetAsync(colsum_a, 0, (size_t)P * sizeof(float), s) != hipSuccess))
-            return check_launch("hd_gemm_tn_limbs_f32");
-        return HD_OK;
-    }
+               "%s: P, Q, ldc must be multiples of 4 and the images and C 16-byte aligned", who);
+    HD_REQUIRE(!colsum_a || is_aligned16(colsum_a), "%s: colsum_a must be 16-byte aligned", who);
     const int tiles_p = (int)((P + TP - 1) / TP), tiles_q = (int)((Q + TQ - 1) / TQ);
     const int tiles = tiles_p * tiles_q;
     const int splits = host_slices(R, tiles);
     int chunk = (int)((R + splits - 1) / splits);
     chunk = (chunk + TR - 1) / TR * TR;
     const int nsl = (int)((R + chunk - 1) / chunk);
-    HD_REQUIRE((int64_t)tiles * nsl < (1LL << 31), "hd_gemm_tn_limbs_f32: too many workgroups");
-    const unsigned grid = (unsigned)((tiles * nsl + 7) / 8 * 8);
+    HD_REQUIRE((int64_t)tiles * nsl < (1LL << 31), "%s: too many workgroups", who);
+    pl.nsl = nsl;
+    pl.count = (size_t)P * Q;
+    pl.count2 = colsum_a ? (size_t)P : 0;
+    pl.C = (float*)C;
+    pl.cs = (float*)colsum_a;
+    pl.ws = pl.cs_ws = nullptr;
+    TnJob& J = pl.job;
+    J.Aimg = (const uint4*)Aimg;
+    J.Bimg = (const uint4*)Bimg;
+    J.R = (int)R; J.P = (int)P; J.Q = (int)Q;
+    J.chunk = chunk; J.tiles_q = tiles_q; J.tiles = tiles; J.total = tiles * nsl;
     if (nsl > 1) {
-        HD_REQUIRE(workspace && is_aligned16(workspace), "hd_gemm_tn_limbs_f32: workspace of hd_gemm_tn_bf16x3_workspace_floats() floats required");
-        HD_REQUIRE(ldc == Q, "hd_gemm_tn_limbs_f32: split reduction needs a contiguous output (ldc == Q)");
-        const size_t count = (size_t)P * Q;
-        float* cs_ws = colsum_a ? (float*)workspace + (size_t)nsl * count : nullptr;
-        gemm_tn_img<<<dim3(grid), 256, 0, s>>>((const uint4*)Aimg, (const uint4*)Bimg, (float*)workspace, (int)R, (int)P, (int)Q,
-                                               (int)Q, chunk, tiles_q, tiles, tiles * nsl, count, cs_ws);
-        const size_t count2 = colsum_a ? (size_t)P : 0;
-        int blocks = (int)(((count + count2) / 4 + 255) / 256);
-        blocks = blocks < 2048 ? blocks : 2048;
-        tn_reduce<<<blocks, 256, 0, s>>>((const float*)workspace, nsl, count, (float*)C, cs_ws, count2, (float*)colsum_a);
+        HD_REQUIRE(workspace && is_aligned16(workspace), "%s: workspace required", who);
+        HD_REQUIRE(ldc == Q, "%s: split reduction needs a contiguous output (ldc == Q)", who);
+        pl.ws = workspace;
+        pl.cs_ws = colsum_a ? workspace + (size_t)nsl * pl.count : nullptr;
+        J.out = pl.ws; J.cs_out = pl.cs_ws; J.ldo = (int)Q; J.slice_stride = pl.count;
     } else {
-        gemm_tn_img<<<dim3(grid), 256, 0, s>>>((const uint4*)Aimg, (const uint4*)Bimg, (float*)C, (int)R, (int)P, (int)Q, (int)ldc,
-                                               chunk, tiles_q, tiles, tiles, 0, (float*)colsum_a);
+        J.out = (float*)C; J.cs_out = (float*)colsum_a; J.ldo = (int)ldc; J.slice_stride = 0;
+    }
+    return HD_OK;
+}
+
+extern "C" int hd_gemm_tn_limbs_f32(const void* Aimg, const void* Bimg, void* C, void* colsum_a, int64_t R, int64_t P,
+                                    int64_t Q, int64_t ldc, void* workspace, void* st) {
+    HD_REQUIRE(R >= 0 && R < (1LL << 31), "hd_gemm_tn_limbs_f32: bad shape R=%lld P=%lld Q=%lld", (long long)R, (long long)P,
+               (long long)Q);
+    hipStream_t s = (hipStream_t)st;
+    if (R == 0) {
+        HD_REQUIRE(P >= 1 && Q >= 1 && C && ldc == Q, "hd_gemm_tn_limbs_f32: empty reduction needs a contiguous output");
+        if (hipMemsetAsync(C, 0, (size_t)P * Q * sizeof(float), s) != hipSuccess ||
+            (colsum_a && hipMemsetAsync(colsum_a, 0, (size_t)P * sizeof(float), s) != hipSuccess))
+            return check_launch("hd_gemm_tn_limbs_f32");
+        return HD_OK;
+    }
+    TnPlan pl;
+    if (const int rc = tn_plan("hd_gemm_tn_limbs_f32", Aimg, Bimg, C, colsum_a, R, P, Q, ldc, (float*)workspace, pl)) return rc;
+    gemm_tn_img<<<dim3((unsigned)((pl.job.total + 7) / 8 * 8)), 256, 0, s>>>(pl.job);
+    if (pl.nsl > 1) {
+        int blocks = (int)(((pl.count + pl.count2) / 4 + 255) / 256);
+        blocks = blocks < 2048 ? blocks : 2048;
+        tn_reduce<<<blocks, 256, 0, s>>>(pl.ws, pl.nsl, pl.count, pl.C, pl.cs_ws, pl.count2, pl.cs);
     }
     return check_launch("hd_gemm_tn_limbs_f32");
+}
+
+// workspace of hd_gemm_tn_limbs_multi_f32: the jobs' own workspaces, one after the other (each a multiple of 4 floats)
+extern "C" int64_t hd_gemm_tn_limbs_multi_workspace_floats(int64_t R, const hd_tn_job* jobs, int n_jobs) {
+    if (!jobs || n_jobs < 1 || n_jobs > kMaxTnJobs) return -1;
+    int64_t total = 0;
+    for (int i = 0; i < n_jobs; ++i) total += hd_gemm_tn_bf16x3_workspace_floats(R, jobs[i].P, jobs[i].Q);
+    return total;
+}
+
+extern "C" int hd_gemm_tn_limbs_multi_f32(int64_t R, const hd_tn_job* jobs, int n_jobs, void* workspace, void* st) {
+    HD_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= kMaxTnJobs, "hd_gemm_tn_limbs_multi_f32: between 1 and %d jobs", kMaxTnJobs);
+    HD_REQUIRE(R >= 0 && R < (1LL << 31), "hd_gemm_tn_limbs_multi_f32: bad row count");
+    HD_REQUIRE(!workspace || is_aligned16(workspace), "hd_gemm_tn_limbs_multi_f32: misaligned workspace");
+    hipStream_t s = (hipStream_t)st;
+    if (R == 0) {                                                 // empty sums: the single-product entry point knows how
+        for (int i = 0; i < n_jobs; ++i)
+            if (const int rc = hd_gemm_tn_limbs_f32(jobs[i].a_img, jobs[i].b_img, jobs[i].c, jobs[i].colsum_a, 0, jobs[i].P,
+                                                    jobs[i].Q, jobs[i].ldc, nullptr, st))
+                return rc;
+        return HD_OK;
+    }
+    TnMulti M{};
+    TnReduceJobs RJ{};
+    M.n = n_jobs;
+    float* ws = (float*)workspace;
+    int64_t most = 0, items = 0;
+    int blocks = 1;
+    TnPlan pl[kMaxTnJobs];
+    for (int i = 0; i < n_jobs; ++i) {
+        const hd_tn_job& j = jobs[i];
+        if (const int rc = tn_plan("hd_gemm_tn_limbs_multi_f32", j.a_img, j.b_img, j.c, j.colsum_a, R, j.P, j.Q, j.ldc, ws, pl[i]))
+            return rc;
+        if (ws) ws += hd_gemm_tn_bf16x3_workspace_floats(R, j.P, j.Q);
+        M.job[i] = pl[i].job;
+        most = pl[i].job.total > most ? pl[i].job.total : most;
+        items += pl[i].job.total;
+        if (pl[i].nsl > 1) {
+            TnReduceJob& r = RJ.job[RJ.n++];
+            r.ws = pl[i].ws; r.nsl = pl[i].nsl; r.count = pl[i].count; r.out = pl[i].C;
+            r.ws2 = pl[i].cs_ws; r.count2 = pl[i].count2; r.out2 = pl[i].cs;
+            const int b = (int)(((r.count + r.count2) / 4 + 255) / 256);
+            blocks = b > blocks ? b : blocks;
+        }
+    }
+    // as many workgroups as the largest job has items (every job of one resident round, as hd_gemm_tn_limbs_f32 cuts
+    // them, fits), a multiple of 8; job j's items are dealt from workgroup rot_j on
+    const int grid = (int)((most + 7) / 8 * 8);
+    int64_t rot = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        M.rot[i] = (int)(rot % grid);
+        rot += pl[i].job.total;
+    }
+    (void)items;
+    gemm_tn_img_multi<<<dim3((unsigned)grid), 256, 0, s>>>(M);
+    if (RJ.n > 0) {
+        blocks = blocks < 1024 ? blocks : 1024;
+        tn_reduce_multi<<<dim3((unsigned)blocks, (unsigned)RJ.n), 256, 0, s>>>(RJ);
+    }
+    return check_launch("hd_gemm_tn_limbs_multi_f32");
 }

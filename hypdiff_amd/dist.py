@@ -146,6 +146,10 @@ class GradBucket:
         lo, hi = self.offsets[id(p)]
         return self.flat[lo:hi].view_as(p)
 
+    def wants_overlap(self):
+        """True when an armed step has real all-reduces to start from the backward pass (more than one rank)."""
+        return bool(self._left) and _collective(self._group)
+
     def delivered(self, p):
         """p's gradient has been WRITTEN (not accumulated) into view_for(p), enqueued on the current stream.  A
         parameter may be delivered once per armed step: a second delivery (the same module applied twice in one loss,

@@ -450,6 +450,21 @@ int hd_adam_step_f32(const hd_adam_job* jobs, int n_jobs, const void* grad_flat,
  * are split; workspace of hd_gemm_tn_bf16x3_workspace_floats(R,P,Q) floats. */
 int hd_gemm_tn_limbs_f32(const void* Aimg, const void* Bimg, void* C, void* colsum_a, int64_t R, int64_t P, int64_t Q,
                          int64_t ldc, void* workspace, void* stream);
+/* Several such products over the SAME R rows in one launch (at most 8 jobs): the five weight gradients of the mlp
+ * denoiser's backward pass (autograd of models/direction_diffusion.py:56-69 under diff.py:113-118), which do not depend
+ * on each other.  Every job is cut and summed exactly as hd_gemm_tn_limbs_f32 cuts and sums it (bit-identical results);
+ * the resident workgroups walk the jobs one after the other without meeting, so four launch ramps, four drains and four
+ * reduction launches go away.  workspace of hd_gemm_tn_limbs_multi_workspace_floats(R, jobs, n) floats (16-byte aligned;
+ * -1: bad arguments). */
+typedef struct hd_tn_job {
+    const void* a_img;
+    const void* b_img;
+    void* c;
+    void* colsum_a;     /* P floats or NULL */
+    int64_t P, Q, ldc;
+} hd_tn_job;
+int64_t hd_gemm_tn_limbs_multi_workspace_floats(int64_t R, const hd_tn_job* jobs, int n_jobs);
+int hd_gemm_tn_limbs_multi_f32(int64_t R, const hd_tn_job* jobs, int n_jobs, void* workspace, void* stream);
 /* out[cols, rows] = in[rows, cols]^T */
 int hd_transpose_f32(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out,
                      void* stream);

@@ -152,3 +152,38 @@ def test_two_chains_at_once_on_two_streams():
         for got in outs[k]:
             assert torch.equal(got, refs[k])
     assert not ops.mlp_chain_failed()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [40, 1000, 15777])
+def test_weight_gradients_in_one_launch_equal_one_launch_each(rows):
+    """hd_gemm_tn_limbs_multi_f32 (the weight gradients of a backward pass as ONE launch of resident workgroups) cuts and
+    sums every product as hd_gemm_tn_limbs_f32 does: results and column sums bit for bit, for ragged shapes, with outputs
+    handed in or allocated, at a row count that needs no slices (40), a few (1000) and the bench's (15 777)."""
+    from hypdiff_amd import autograd as ag, ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(rows)
+    shapes = [(136, 72), (200, 136), (68, 200), (512, 700), (900, 800)]
+    imgs = []
+    for P, Q in shapes:
+        a = torch.randn(rows, P, generator=g).to(dev)
+        b = torch.randn(rows, Q, generator=g).to(dev)
+        imgs.append((ops.limb_pack(a, "bf16x3"), ops.limb_pack(b, "bf16x3"), a, b))
+    single = [ag.gemm_tn_limbs(ai, bi) for ai, bi, _, _ in imgs]
+    outs = [None, torch.empty(200, 136, device=dev), None, torch.empty(512, 700, device=dev), None]
+    css = [None, torch.empty(200, device=dev), None, None, torch.empty(900, device=dev)]
+    multi = ag.gemm_tn_limbs_multi([(ai, bi, o, c) for (ai, bi, _, _), o, c in zip(imgs, outs, css)])
+    torch.cuda.synchronize()
+    for (w0, c0), (w1, c1), (_, _, a, b), o, c in zip(single, multi, imgs, outs, css):
+        assert torch.equal(w0, w1) and torch.equal(c0, c1)
+        if o is not None:
+            assert w1.data_ptr() == o.data_ptr()
+        if c is not None:
+            assert c1.data_ptr() == c.data_ptr()
+        ref = a.double().t() @ b.double()
+        bound = 2e-6 * (a.double().abs().t() @ b.double().abs())
+        assert bool(((w1.double()[: ref.shape[0], : ref.shape[1]] - ref).abs() <= bound + 1e-30).all())
+    # a second call on the same stream reuses the workspace: same bits
+    again = ag.gemm_tn_limbs_multi([(ai, bi, None, None) for ai, bi, _, _ in imgs])
+    for (w0, c0), (w1, c1) in zip(single, again):
+        assert torch.equal(w0, w1) and torch.equal(c0, c1)

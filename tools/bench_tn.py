@@ -51,6 +51,25 @@ def main():
         us = e0.elapsed_time(e1) * 1e3 / reps
         tot["images"] = tot.get("images", 0.0) + us
         print(f"images  {R}x{P}x{Q}: {us:7.1f} us  {2.0 * R * P * Q / us * 1e-6:6.1f} TFLOP/s", flush=True)
+    # the five image products as ONE launch (hd_gemm_tn_limbs_multi_f32)
+    jobs = []
+    for P, Q in shapes:
+        ai = ops.limb_pack(torch.randn(R, P, device="cuda", generator=g), "bf16x3")
+        bi = ops.limb_pack(torch.randn(R, Q, device="cuda", generator=g), "bf16x3")
+        Pp, Qp = (P + 3) // 4 * 4, (Q + 3) // 4 * 4
+        jobs.append((ai, bi, torch.empty(Pp, Qp, device="cuda"), torch.empty(Pp, device="cuda")))
+    for _ in range(5):
+        hag.gemm_tn_limbs_multi(jobs)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        hag.gemm_tn_limbs_multi(jobs)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    fl = sum(2.0 * R * P * Q for P, Q in shapes)
+    tot["images, one launch"] = us
+    print(f"images, one launch: {us:7.1f} us  {fl / us * 1e-6:6.1f} TFLOP/s", flush=True)
     print({k: round(v, 1) for k, v in tot.items()})
 
 
