@@ -176,25 +176,26 @@ __device__ __forceinline__ lbf16x8 tr_frag(const __attribute__((address_space(3)
     return __builtin_bit_cast(lbf16x8, f);
 }
 
-// one product C = A^T B cut into `tiles` 128 x 128 tiles and row slices of `chunk` rows: work item vid = slice * tiles + tile
+// one product C = A^T B cut into `tiles` 128 x 128 tiles and `nsl` row slices (whole slabs, dealt evenly): work item vid = slice * tiles + tile
 struct TnJob {
     const uint4* Aimg;
     const uint4* Bimg;
     float* out;               // C itself (one slice) or the workspace of partial tiles
     float* cs_out;            // column sums of A (per slice), or null
-    int R, P, Q, ldo, chunk, tiles_q, tiles, total;
+    int R, P, Q, ldo, tiles_q, tiles, total;
+    int slabs_q, slabs_rem;   // slice s covers slabs_q + (s < slabs_rem) slabs of 32 rows: slices differ by one slab at most
     size_t slice_stride;
 };
 
 // work item `vid` of job J by this workgroup; `lds` = 48 KB, free on entry (every wavefront holds no fragment of it) and on exit
 __device__ __forceinline__ void tn_img_item(const TnJob& J, int vid, uint4* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int R = J.R, P = J.P, Q = J.Q, ldo = J.ldo;
+    const int P = J.P, Q = J.Q, ldo = J.ldo;
     const int tile = vid % J.tiles, slice = vid / J.tiles;
     const int tp = tile / J.tiles_q, tq = tile - tp * J.tiles_q;
     const int p0 = tp * TP, q0 = tq * TQ;
-    const int r_begin = slice * J.chunk, r_end = r_begin + J.chunk < R ? r_begin + J.chunk : R;
-    const int nslab = (r_end - r_begin + TR - 1) / TR;
+    const int nslab = J.slabs_q + (slice < J.slabs_rem ? 1 : 0);
+    const int r_begin = (slice * J.slabs_q + (slice < J.slabs_rem ? slice : J.slabs_rem)) * TR;
     // staging: wavefront w brings sub-tiles 12 w .. 12 w + 11 (waves 0, 1: A; 2, 3: B); lane L fetches the chunk of column
     // half L >> 5, row (L & 31) ^ 4 (L >> 5) of the slab, into position L of the sub-tile
     const int op = wave >> 1;
@@ -236,7 +237,13 @@ __device__ __forceinline__ void tn_img_item(const TnJob& J, int vid, uint4* lds)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = lf32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const bool do_cs = J.cs_out != nullptr && tq == 0 && wc == 0;  // uniform over the wavefront
+    // column sums of A (the bias gradient): the eight 16-column groups (wr, i) of a tile row are dealt over the wavefronts
+    // (tq, wc) of that tile row that hold their fragments, so that no tile is 12 % longer than its neighbours (tiles that
+    // share rows stay in phase in the L2); the sum of a column is the same sequence of products wherever it runs
+    const int cs_slots = 2 * J.tiles_q, cs_mine = 2 * tq + wc;
+    bool cs_own[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cs_own[i] = J.cs_out != nullptr && (wr * 4 + i) % cs_slots == cs_mine;   // wavefront-uniform
     const lbf16x8 ones = __builtin_bit_cast(lbf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
     if (nslab > 0) stage(0);
     for (int t = 0; t < nslab; ++t) {
@@ -263,7 +270,7 @@ __device__ __forceinline__ void tn_img_item(const TnJob& J, int vid, uint4* lds)
 #undef HD_MM
                 acc[i][j] = c;
             }
-            if (do_cs) {
+            if (cs_own[i]) {
                 lf32x4 c = csa[i];
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[i][2], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[i][1], c, 0, 0, 0);
@@ -272,11 +279,11 @@ __device__ __forceinline__ void tn_img_item(const TnJob& J, int vid, uint4* lds)
             }
         }
     }
-    if (do_cs && kq == 0) {                                       // every row of the ones product is the column sum
+    if (kq == 0) {                                                // every row of the ones product is the column sum
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = p0 + wr * 64 + i * 16 + r16;
-            if (p < P) J.cs_out[(size_t)slice * P + p] = csa[i][0];
+            if (cs_own[i] && p < P) J.cs_out[(size_t)slice * P + p] = csa[i][0];
         }
     }
     float* o = J.out + (size_t)slice * J.slice_stride;
@@ -444,10 +451,9 @@ static int tn_plan(const char* who, const void* Aimg, const void* Bimg, void* C,
     HD_REQUIRE(!colsum_a || is_aligned16(colsum_a), "%s: colsum_a must be 16-byte aligned", who);
     const int tiles_p = (int)((P + TP - 1) / TP), tiles_q = (int)((Q + TQ - 1) / TQ);
     const int tiles = tiles_p * tiles_q;
-    const int splits = host_slices(R, tiles);
-    int chunk = (int)((R + splits - 1) / splits);
-    chunk = (chunk + TR - 1) / TR * TR;
-    const int nsl = (int)((R + chunk - 1) / chunk);
+    const int slabs = (int)((R + TR - 1) / TR);
+    int nsl = host_slices(R, tiles);
+    nsl = nsl < slabs ? nsl : slabs;
     HD_REQUIRE((int64_t)tiles * nsl < (1LL << 31), "%s: too many workgroups", who);
     pl.nsl = nsl;
     pl.count = (size_t)P * Q;
@@ -459,7 +465,8 @@ static int tn_plan(const char* who, const void* Aimg, const void* Bimg, void* C,
     J.Aimg = (const uint4*)Aimg;
     J.Bimg = (const uint4*)Bimg;
     J.R = (int)R; J.P = (int)P; J.Q = (int)Q;
-    J.chunk = chunk; J.tiles_q = tiles_q; J.tiles = tiles; J.total = tiles * nsl;
+    J.slabs_q = slabs / nsl; J.slabs_rem = slabs % nsl;
+    J.tiles_q = tiles_q; J.tiles = tiles; J.total = tiles * nsl;
     if (nsl > 1) {
         HD_REQUIRE(workspace && is_aligned16(workspace), "%s: workspace required", who);
         HD_REQUIRE(ldc == Q, "%s: split reduction needs a contiguous output (ldc == Q)", who);
