@@ -420,10 +420,16 @@ def gemm_limbs(a, w, bias=None, epi=0, resid=None, want_f32=True, want_limbs=Fal
     c = None
     if want_f32:
         c = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=dev)
-    cl = limb_empty(M, N, dev, fmt, scales=out_scales) if want_limbs else None
     ldc = c.stride(0) if c is not None else (resid.stride(0) if resid is not None else N)
     if resid is not None and c is not None:
         assert resid.stride(0) == c.stride(0)
+    if (fmt == "bf16x3" and GEMM_VIA_CHAIN and not _NO_MLP_CHAIN and resid is None and epi in (0, 1)
+            and M >= MLP_CHAIN_MIN_ROWS and N % 16 == 0):
+        # many rows: the one-launch chain's 128 x 128 tiles, as a chain of one layer (same bits as hd_gemm_limbs_f32)
+        o = _mlp_chain_launch(a, [{"w": w, "bias": bias, "epi": epi, "img": want_limbs, "f32": c if want_f32 else False}],
+                              label="gemm_limbs")[0]
+        return c, o[0]
+    cl = limb_empty(M, N, dev, fmt, scales=out_scales) if want_limbs else None
     ev = GEMM_EVENTS
     if ev is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -528,6 +534,7 @@ def linear_chain(x, layers):
 # ---- the whole stack as ONE persistent launch over many rows (csrc/gemm_chain.hip) ----
 MLP_CHAIN_MIN_ROWS = 4096                                     # below this the per-layer launches are not round-bound
 _NO_MLP_CHAIN = bool(os.environ.get("HD_NO_MLP_CHAIN"))       # A/B knob: one hd_gemm_limbs_f32 launch per layer
+GEMM_VIA_CHAIN = os.environ.get("HD_GEMM_VIA_CHAIN", "1") != "0"   # a single limb GEMM over many rows as a chain of one layer
 _mlp_chain_ws = {}
 
 
@@ -538,7 +545,7 @@ def mlp_chain_ok(a, layers):
             and all(w.dtype == torch.float32 for w, _, _ in layers))
 
 
-def _mlp_chain_launch(a, specs):
+def _mlp_chain_launch(a, specs, label="mlp_chain"):
     """One hd_mlp_chain_limbs_f32 launch.  specs: one dict per layer with w (LimbImage of the weight), bias, epi and the
     outputs wanted: img (limb image), f32 (fp32 tensor, or a tensor to write into), z (fp32 pre-activation), aux (epi 3:
     z of the layer below).  fp32 rows are padded to 64 bytes as gemm_limbs_train's are.  Returns [(img, f32, z), ...]."""
@@ -586,7 +593,7 @@ def _mlp_chain_launch(a, specs):
     _lib.call("hd_mlp_chain_limbs_f32", _p(a.buf), M, arr, len(specs), _p(ws), ws.numel() * 4, _stream())
     if ev is not None:
         e1.record()
-        ev.append((e0, e1, flops, nbytes, "mlp_chain"))
+        ev.append((e0, e1, flops, nbytes, label))
     return outs
 
 

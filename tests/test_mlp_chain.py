@@ -187,3 +187,27 @@ def test_weight_gradients_in_one_launch_equal_one_launch_each(rows):
     again = ag.gemm_tn_limbs_multi([(ai, bi, None, None) for ai, bi, _, _ in imgs])
     for (w0, c0), (w1, c1) in zip(single, again):
         assert torch.equal(w0, w1) and torch.equal(c0, c1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(15777, 512, 512), (4100, 272, 130 * 16)])
+def test_single_gemm_as_a_chain_of_one_layer(shape, monkeypatch):
+    """ops.gemm_limbs over many rows through the chain kernel's wide tiles (a chain of ONE layer) = hd_gemm_limbs_f32,
+    bit for bit: fp32 output and limb image, with and without bias + GELU."""
+    from hypdiff_amd import ops
+    M, K, N = shape
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(M + N)
+    a = ops.limb_pack(torch.randn(M, K, generator=g).to(dev), "bf16x3")
+    w = ops.limb_pack(torch.randn(N, K, generator=g).to(dev) / K ** 0.5, "bf16x3")
+    b = torch.randn(N, generator=g).to(dev)
+    for bias, epi, limbs in ((None, 0, False), (b, 1, True)):
+        monkeypatch.setattr(ops, "GEMM_VIA_CHAIN", False)
+        c0, l0 = ops.gemm_limbs(a, w, bias, epi=epi, want_limbs=limbs)
+        monkeypatch.setattr(ops, "GEMM_VIA_CHAIN", True)
+        c1, l1 = ops.gemm_limbs(a, w, bias, epi=epi, want_limbs=limbs)
+        torch.cuda.synchronize()
+        assert torch.equal(c0, c1)
+        if limbs:
+            assert torch.equal(ops.limb_unpack(l0), ops.limb_unpack(l1))
+    assert not ops.mlp_chain_failed()
