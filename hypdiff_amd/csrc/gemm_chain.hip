@@ -89,6 +89,7 @@ struct ChainArgs {
     int n_layers, M, tiles_m;
     int delay_ticks;         // start-up stagger of every second workgroup (0 = none)
     unsigned long long* dbg; // HD_MLP_CHAIN_DEBUG_PTR: 8 wall-clock stamps per workgroup (probes), or null
+    int gang;                // wide row blocks of a queue handed out in gangs of this many (decode)
     int flags;               // debugging (HD_MLP_CHAIN_FLAGS): 4 = no pull-ahead (every successor resolved blocking), 8 = count slow paths
 };
 
@@ -141,7 +142,7 @@ __device__ __forceinline__ int queue_blocks(int q, int tiles_m) { return q < til
 // (three runs of kMaxLayers) plus the eight queue lengths, in LDS: indexed by values that live in vector registers (thread
 // 0's successor bookkeeping), where an index into the kernel arguments would be a blocking global load.
 constexpr int kNarrow = 1 << 20;
-constexpr int TAB_TW = 0, TAB_T64 = kMaxLayers, TAB_NF = 2 * kMaxLayers, TAB_QLEN = 3 * kMaxLayers, TAB_SIZE = 3 * kMaxLayers + 8;
+constexpr int TAB_TW = 0, TAB_T64 = kMaxLayers, TAB_NF = 2 * kMaxLayers, TAB_QLEN = 3 * kMaxLayers, TAB_GANG = 3 * kMaxLayers + 8, TAB_SIZE = 3 * kMaxLayers + 9;
 // wide row blocks of layer l in queue q (which holds nq row blocks)
 __device__ __forceinline__ int wide_blocks(const int* tab, int l, int q, int nq) {
     const int n = (tab[TAB_NF + l] - q + 7) >> 3;
@@ -167,9 +168,18 @@ __device__ __forceinline__ void decode(const int* tab, int n_layers, int tiles_m
     }
     const int tw = tab[TAB_TW + l], t64 = tab[TAB_T64 + l];
     int j;
-    if (idx < nw * tw) {
-        j = idx / tw;
-        tn = idx - j * tw;
+    // wide row blocks in gangs of G: the tiles of a gang are handed out column tile by column tile (tn, then the row block
+    // within the gang), so that the G tiles that read one slice of the W image start together (G = 1: N fastest)
+    const int G = tab[TAB_GANG], gsz = G * tw, full = nw / G * gsz;
+    if (idx < full) {
+        const int grp = idx / gsz, r = idx - grp * gsz;
+        tn = r / G;
+        j = grp * G + (r - tn * G);
+    } else if (idx < nw * tw) {
+        const int r = idx - full;
+        j = r / tw;
+        tn = r - j * tw;
+        j += nw / G * G;
     } else {
         const int r = idx - nw * tw;
         j = r / t64;
@@ -228,6 +238,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     }
     __syncthreads();
     if (threadIdx.x < 8) tab[TAB_QLEN + threadIdx.x] = queue_items(tab, P.n_layers, P.tiles_m, threadIdx.x);
+    if (threadIdx.x == 8) tab[TAB_GANG] = P.gang;
     __syncthreads();
     // ---- thread 0's private scheduling state ----
     int curq = my_xcd, tried = 0;                             // queue being pulled from, queues found empty so far
@@ -734,15 +745,16 @@ extern "C" int hd_mlp_chain_limbs_f32(const void* A0, int64_t rows, const hd_mlp
     P.n_layers = n_layers;
     P.M = (int)rows;
     P.tiles_m = (int)((rows + 127) / 128);
-    struct Knobs { int n_cu, delay_ns, flags, reload, per_cu, tail, grid; };
+    struct Knobs { int n_cu, delay_ns, flags, reload, per_cu, tail, grid, gang; };
     static Knobs knobs = [] {
-        Knobs k{256, 0, 0, 0, 2, 0, 0};
+        Knobs k{256, 0, 0, 0, 2, 0, 0, 1};
         if (const char* e = getenv("HD_MLP_CHAIN_PER_CU")) k.per_cu = atoi(e);
         if (const char* e = getenv("HD_MLP_CHAIN_DELAY_NS")) k.delay_ns = atoi(e);
         if (const char* e = getenv("HD_MLP_CHAIN_FLAGS")) k.flags = atoi(e);
         if (const char* e = getenv("HD_GEMM_TUNE_RELOAD")) k.reload = atoi(e);
         if (const char* e = getenv("HD_MLP_CHAIN_TAIL")) k.tail = atoi(e);
         if (const char* e = getenv("HD_MLP_CHAIN_GRID")) k.grid = atoi(e);
+        if (const char* e = getenv("HD_MLP_CHAIN_GANG")) k.gang = atoi(e);
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -754,6 +766,7 @@ extern "C" int hd_mlp_chain_limbs_f32(const void* A0, int64_t rows, const hd_mlp
         if (const char* e = getenv("HD_MLP_CHAIN_FLAGS")) knobs.flags = atoi(e);
         if (const char* e = getenv("HD_MLP_CHAIN_PER_CU")) knobs.per_cu = atoi(e);
         if (const char* e = getenv("HD_MLP_CHAIN_TAIL")) knobs.tail = atoi(e);
+        if (const char* e = getenv("HD_MLP_CHAIN_GANG")) knobs.gang = atoi(e);
     }
     if (knobs.tail < 0 || knobs.tail > 100) knobs.tail = 0;
     const int per_cu = knobs.per_cu >= 1 && knobs.per_cu <= 2 ? knobs.per_cu : 2;
@@ -805,6 +818,7 @@ extern "C" int hd_mlp_chain_limbs_f32(const void* A0, int64_t rows, const hd_mlp
     HD_REQUIRE(items < (1LL << 30), "hd_mlp_chain_limbs_f32: too many tiles");
     P.delay_ticks = knobs.delay_ns / 10;
     P.flags = knobs.flags;
+    P.gang = knobs.gang >= 1 && knobs.gang <= 16 ? knobs.gang : 1;
     P.dbg = nullptr;
     if (knobs.reload)
         if (const char* e = getenv("HD_MLP_CHAIN_DEBUG_PTR")) P.dbg = (unsigned long long*)strtoull(e, nullptr, 0);

@@ -21,11 +21,16 @@ def _layers(dims, seed, dev, bias=True):
 
 
 def _per_layer(ops, a, layers):
+    """one hd_gemm_limbs_f32 launch per layer (the per-layer kernel itself, not the chain kernel run layer by layer)"""
     xf = None
-    for i, (w, b, epi) in enumerate(layers):
-        last = i == len(layers) - 1
-        wl, _ = ops.weight_limbs(w, "bf16x3")
-        xf, a = ops.gemm_limbs(a, wl, b, epi=epi, want_f32=last, want_limbs=not last)
+    via, ops.GEMM_VIA_CHAIN = ops.GEMM_VIA_CHAIN, False
+    try:
+        for i, (w, b, epi) in enumerate(layers):
+            last = i == len(layers) - 1
+            wl, _ = ops.weight_limbs(w, "bf16x3")
+            xf, a = ops.gemm_limbs(a, wl, b, epi=epi, want_f32=last, want_limbs=not last)
+    finally:
+        ops.GEMM_VIA_CHAIN = via
     return xf
 
 

@@ -11,6 +11,7 @@ import torch
 os.environ["HD_GEMM_TUNE_RELOAD"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hypdiff_amd import ops  # noqa: E402
+ops.GEMM_VIA_CHAIN = False   # per-layer launches = the per-layer kernel (hd_gemm_limbs_f32)
 
 
 def timeit(fn, iters=50):
