@@ -27,6 +27,7 @@ import socket
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 import types
 
@@ -97,6 +98,66 @@ def timed_steps(w, T, steps, warmup, barrier, ops, dist, device, instrument=Fals
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     return elapsed, events, phase or []
+
+
+def progress(msg):
+    """HD_BENCH_VERBOSE=1: one stderr line per leg and rank (where a multi-rank run is, should it stop)"""
+    if os.environ.get("HD_BENCH_VERBOSE") == "1":
+        sys.stderr.write("[bench rank %s %.1fs] %s\n" % (os.environ.get("RANK", "0"), time.perf_counter() - _T0, msg))
+        sys.stderr.flush()
+
+
+_T0 = time.perf_counter()
+
+
+def stage_collectives_through_host(dist):
+    """Rehearsal mode only (HD_BENCH_SHARE_GPU=1, backend gloo): every collective on device tensors becomes blocking copy
+    to the host -> gloo on host tensors -> copy back.  gloo's own path for device tensors takes a fresh stream of torch's
+    pool for every operation; with more HIP streams in use than hardware queues (GPU_MAX_HW_QUEUES = 4) its cross-stream
+    waits never completed on the box (the second training step stopped; 16 queues: the row-sharded leg's eighth or so
+    all-gather; tools/probes/rehearse_train.py).  RCCL runs every collective of a process group on ONE stream."""
+    class Done:
+        def wait(self):
+            return True
+
+    def host(t):
+        return t.detach().cpu() if t.is_cuda else t
+
+    raw = {n: getattr(dist, n) for n in ("all_reduce", "broadcast", "all_gather_into_tensor", "all_to_all_single", "all_gather")}
+
+    def finish(pairs, async_op):
+        for dev_t, host_t in pairs:
+            if dev_t.is_cuda:
+                dev_t.copy_(host_t)
+        return Done() if async_op else None
+
+    def all_reduce(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
+        h = host(t)
+        raw["all_reduce"](h, op=op, group=group)
+        return finish([(t, h)], async_op)
+
+    def broadcast(t, src=0, group=None, async_op=False):
+        h = host(t)
+        raw["broadcast"](h, src=src, group=group)
+        return finish([(t, h)], async_op)
+
+    def all_gather_into_tensor(out, inp, group=None, async_op=False):
+        ho = host(out)
+        raw["all_gather_into_tensor"](ho, host(inp).contiguous(), group=group)
+        return finish([(out, ho)], async_op)
+
+    def all_to_all_single(out, inp, output_split_sizes=None, input_split_sizes=None, group=None, async_op=False):
+        ho = host(out)
+        raw["all_to_all_single"](ho, host(inp).contiguous(), output_split_sizes, input_split_sizes, group=group)
+        return finish([(out, ho)], async_op)
+
+    def all_gather(outs, inp, group=None, async_op=False):
+        hs = [host(o) for o in outs]
+        raw["all_gather"](hs, host(inp), group=group)
+        return finish(list(zip(outs, hs)), async_op)
+
+    dist.all_reduce, dist.broadcast, dist.all_gather_into_tensor = all_reduce, broadcast, all_gather_into_tensor
+    dist.all_to_all_single, dist.all_gather = all_to_all_single, all_gather
 
 
 def host_batch(seed, dim, feat=20):
@@ -243,13 +304,14 @@ def train_leg(w, dim, device, steps, warmup, barrier, dist):
     for _ in range(warmup):
         tr.step(loss_fn)
     barrier()
-    hdist.WAIT_EVENTS = []
+    hdist.WAIT_EVENTS = None if os.environ.get("HD_BENCH_NO_WAIT_EVENTS") == "1" else []
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
         loss = tr.step(loss_fn)
+        progress("training step %d issued" % i)
     barrier()
     dt = time.perf_counter() - t0
-    waits, hdist.WAIT_EVENTS = hdist.WAIT_EVENTS, None
+    waits, hdist.WAIT_EVENTS = hdist.WAIT_EVENTS or [], None
     exposed_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in waits) / steps
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -337,7 +399,7 @@ def launch_ranks(n, argv, dry):
     MASTER_PORT in their environment, exactly what torch.distributed.run would set -- and waits.  Rank 0's stdout is
     forwarded (its last line is the JSON line); the other ranks' stdout goes to stderr.  Exit status: the first
     non-zero status of any rank (the remaining ranks are then terminated by PID), else 0."""
-    if not dry:
+    if not dry and os.environ.get("HD_BENCH_SHARE_GPU") != "1":
         have = torch.cuda.device_count()
         if have < n:
             sys.stderr.write(f"bench.py: --gpus {n} but only {have} GPU(s) visible\n")
@@ -366,9 +428,36 @@ def launch_ranks(n, argv, dry):
                 for q in live:
                     procs[q].terminate()          # exact PIDs of the children started above
     out0.seek(0)
-    sys.stdout.write(out0.read())
+    for line in out0.read().splitlines():         # the JSON line to stdout; anything else rank 0 printed (gloo's connection
+        dst = sys.stdout if line.lstrip().startswith("{") else sys.stderr      # notice goes to stdout) to stderr
+        dst.write(line + "\n")
     sys.stdout.flush()
     return rc if rc >= 0 else 128 - rc
+
+
+def start_legs_watchdog(out, rank, limit_s, first_leg):
+    """A secondary leg that stops with more than one rank (a rank that left the leg early on an error, a collective that
+    never completes) must not cost the headline: when the returned event has not been set `limit_s` seconds from now,
+    rank 0 prints the line as it stands -- the unfinished leg (current_leg[0]) as an error entry -- and every rank ends
+    its process (each rank runs its own watchdog).  limit_s <= 0: no watchdog.  Returns (done_event, current_leg)."""
+    done, current_leg = threading.Event(), [first_leg]
+
+    def watchdog():
+        if done.wait(limit_s):
+            return
+        if rank == 0:
+            out[current_leg[0]] = {"error": "leg not finished %d s after the headline steps (--legs-timeout): abandoned; the "
+                                            "headline figures of this line were measured before it and are unaffected" % limit_s}
+            out.setdefault("cpu_baseline", None)
+            sys.stdout.write(json.dumps(out) + "\n")
+            sys.stdout.flush()
+        sys.stderr.write("bench.py: rank %d: secondary leg '%s' exceeded --legs-timeout; exiting\n" % (rank, current_leg[0]))
+        sys.stderr.flush()
+        os._exit(0)
+
+    if limit_s > 0:
+        threading.Thread(target=watchdog, daemon=True).start()
+    return done, current_leg
 
 
 def dry_run(a, rank, world):
@@ -394,8 +483,10 @@ def dry_run(a, rank, world):
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_gather(per_rank, rows)
     rows_per_gpu = [int(r.item()) for r in per_rank]
+    stall = os.environ.get("HD_BENCH_DRY_STALL_RANK")      # test hook: that rank never joins the "leg" below
+    out = None
     if rank == 0:
-        print(json.dumps({"metric": "latent node-steps/sec (HGCN encode + DDPM step)",
+        out = ({"metric": "latent node-steps/sec (HGCN encode + DDPM step)",
                           "value": None, "unit": "node-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": float(el.item()) / a.steps * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
                           "data": "synthetic", "dry": True,
@@ -403,7 +494,15 @@ def dry_run(a, rank, world):
                                                  "value is not a performance number",
                                      "rows_per_gpu": rows_per_gpu, "backend": a.backend, "checksum": chk,
                                      "launched_by": "bench.py launcher" if os.environ.get("HD_BENCH_LAUNCHED") else
-                                                    ("external launcher" if world > 1 else "single process")}}))
+                                                    ("external launcher" if world > 1 else "single process")}})
+    if stall is not None and world > 1:
+        done, _ = start_legs_watchdog(out, rank, a.legs_timeout, "dry_stall")
+        if rank == int(stall):
+            time.sleep(3600)
+        dist.barrier()                                     # never completes: the watchdog ends every rank
+        done.set()
+    if rank == 0:
+        print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -427,6 +526,9 @@ def main():
     ap.add_argument("--train-steps", type=int, default=20, help="steps of the secondary training leg (0 = skip)")
     ap.add_argument("--sharded-steps", type=int, default=5, help="steps of the secondary row-sharded leg (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="headline steps only (profiling runs)")
+    ap.add_argument("--legs-timeout", type=int, default=420,
+                    help="more than one rank: seconds the secondary legs may take in all before the line is printed without "
+                         "the unfinished one (0 = no limit)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo with --dry)")
     ap.add_argument("--dry", action="store_true", help="no GPU, no kernels: launcher / rendezvous / JSON plumbing only")
     a = ap.parse_args()
@@ -445,17 +547,29 @@ def main():
     if a.gpus != world:
         sys.stderr.write(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: running the {world} rank(s) of the launcher\n")
     dist = None
+    # HD_BENCH_SHARE_GPU=1: rehearsal of the N-rank path on a box with ONE GPU -- every rank on cuda:0, backend gloo (RCCL
+    # refuses two ranks on one device); the line says so (config.rehearsal) and its value is not a scaling figure
+    share = os.environ.get("HD_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share or world == 1 else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(a.backend, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    device = f"cuda:{local_rank if world > 1 else 0}"
+        if a.backend == "nccl":
+            dist.init_process_group(a.backend, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(a.backend)
+            if share:
+                stage_collectives_through_host(dist)
+    device = f"cuda:{dev_index}"
+    if os.environ.get("HD_BENCH_VERBOSE") == "1":      # a run that stops: every thread's Python stack after HD_BENCH_DUMP_S seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ.get("HD_BENCH_DUMP_S", "600")), exit=False)
+    progress("process group up (world %d, backend %s), device %s" % (world, a.backend if world > 1 else "-", device))
 
     from hypdiff_amd import ops
     T = a.timesteps
     w = build_workload(a.dim, T, 1432 + rank, device)
+    progress("workload resident")
 
     def barrier():
         torch.cuda.synchronize()
@@ -491,6 +605,7 @@ def main():
                                "pipeline gets") + "; run before the headline steps (first on the idle chip)"})
         finally:
             w.pop("side_stream", None)
+    progress("secondary stream-arrangement leg done")
     if side is not None:
         w["side_stream"] = side
     try:
@@ -498,6 +613,7 @@ def main():
     finally:
         w.pop("side_stream", None)
     untimed_before += a.warmup
+    progress("headline steps done")
     el_inst, events, phase = timed_steps(w, T, a.steps, min(a.warmup, 3), barrier, ops, dist, device, instrument=True)
     rows_per_gpu = [w["n"]]
     if dist is not None:
@@ -547,6 +663,8 @@ def main():
                               "two HIP streams, software-pipelined across batches: step i encodes batch i % 2 while "
                               "p_sample advances the latents of batch (i + 1) % 2; joined per step",
                    "priming_steps": 0,
+                   **({"rehearsal": "HD_BENCH_SHARE_GPU=1: all %d ranks share cuda:0 over backend %s; exercises the N-rank "
+                                    "code path only, NOT a scaling measurement" % (world, a.backend)} if share and world > 1 else {}),
                    "order": ("secondary leg in the other stream arrangement (%d untimed-for-the-headline steps), then "
                              % (untimed_before - a.warmup) if other else "") +
                             "W warm-up + K timed headline steps, then the instrumented per-kernel pass, then the other legs; "
@@ -573,6 +691,8 @@ def main():
                         "p_sample_ms": dif_ms,
                         "ddpm_node_steps_per_s_per_gpu": w["n"] / (dif_ms * 1e-3) if dif_ms else None,
                         "note": "HIP-event time of the two phases of one step on rank 0, instrumented pass (SURVEY.md 8d)"}
+    # From here on only secondary legs run; with more than one rank a watchdog keeps a leg that stops from costing the headline
+    legs_done, current_leg = start_legs_watchdog(out, rank, a.legs_timeout if world > 1 else 0, "other_gemm_modes")
     if not a.no_exact_leg:
         # the same K steps under the other fp32 GEMM kernels, for comparison
         mode = ops.GEMM_MODE
@@ -603,18 +723,24 @@ def main():
         out[other[0]] = other[1]
     if a.train_steps > 0:
         try:
+            progress("instrumented pass and comparison legs done; training leg")
+            current_leg[0] = "train"
             out["train"] = train_leg(w, a.dim, device, a.train_steps, 3, barrier, dist)
         except Exception as e:                      # never lose the headline line to the secondary leg
             out["train"] = {"error": repr(e)}
     if a.sharded_steps > 0:
         try:
+            progress("row-sharded leg")
+            current_leg[0] = "sharded"
             out["sharded"] = sharded_leg(device, rank, world, a.sharded_steps, 2, barrier, dist)
         except Exception as e:
             out["sharded"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        progress("CPU baseline")
         out["cpu_baseline"] = cpu_baseline(w, a.dim, T)
     elif rank == 0:
         out["cpu_baseline"] = None
+    legs_done.set()
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -77,3 +77,15 @@ def test_rank_mode_under_an_external_launcher():
     j = _json_line(outs[0][0])
     assert j["n_gpus"] == 2 and j["config"]["launched_by"] == "external launcher"
     assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]      # only rank 0 prints
+
+
+def test_a_stopped_secondary_leg_does_not_cost_the_line():
+    """rank 1 never joins a collective after the headline (HD_BENCH_DRY_STALL_RANK: the dry run's stand-in for a secondary
+    leg that stops with more than one rank): after --legs-timeout seconds every rank's watchdog ends its process, rank 0
+    having printed the line with the unfinished leg as an error entry; exit status 0"""
+    r = _run(["--gpus", "2", "--dry", "--backend", "gloo", "--steps", "2", "--legs-timeout", "3"],
+             env={"HD_BENCH_DRY_STALL_RANK": "1"}, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 2 and "not finished 3 s" in j["dry_stall"]["error"]
+    assert "exceeded --legs-timeout" in r.stderr
