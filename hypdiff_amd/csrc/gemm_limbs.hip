@@ -184,46 +184,61 @@ constexpr int kMaxPackJobs = 16;
 struct PackJob { const float* src; uint4* out; int64_t ld; int rows, cols, nslab, trans; unsigned block0; };
 struct PackJobs { int n; PackJob j[kMaxPackJobs]; };
 
+// One workgroup per (128-row block, 32-column slab) of an image: the 128 x 32 fp32 values go through LDS so that both
+// sides are in runs -- the source is read in 128-byte row pieces (or, transposed, in 512-byte column pieces), the image is
+// written in 2-KiB runs of one (limb, chunk column).  (Round 3: a thread used to fetch its own 32 bytes of its own row,
+// 33 us for the ten weight images of the denoiser; same bits.)
 __global__ __launch_bounds__(256) void limb_pack_multi(const PackJobs jobs) {
+    __shared__ float st[128][33];
     int k = 0;
     while (k + 1 < jobs.n && blockIdx.x >= jobs.j[k + 1].block0) ++k;
     const PackJob& J = jobs.j[k];
-    const int64_t id = (int64_t)(blockIdx.x - J.block0) * 256 + threadIdx.x;   // ((rb * nslab + s) * 4 + kc) * 128 + r
-    const int r = (int)(id & 127);
-    const int64_t q = id >> 7;
-    const int kc = (int)(q & 3);
-    const int64_t tile = q >> 2;
+    const int64_t tile = (int64_t)(blockIdx.x - J.block0);                   // rb * nslab + s
     const int s = (int)(tile % J.nslab);
     const int64_t rb = tile / J.nslab;
-    const int64_t row = rb * 128 + r;
-    const int c0 = s * 32 + kc * 8;
-    float v[8];
+    const int t = threadIdx.x;
+    if (J.trans) {                                                            // image (r, c) = src[c][r]
+        const int r = t & 127;
+        const int64_t row = rb * 128 + r;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = 0.f;
-    if (row < J.rows) {
-        if (J.trans) {
+        for (int i = 0; i < 16; ++i) {
+            const int c = (t >> 7) + 2 * i, cg = s * 32 + c;
+            st[r][c] = (row < J.rows && cg < J.cols) ? J.src[(int64_t)cg * J.ld + row] : 0.f;
+        }
+    } else {
+        const int c = (t & 7) * 4, cg = s * 32 + c;
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (c0 + e < J.cols) v[e] = J.src[(int64_t)(c0 + e) * J.ld + row];
-        } else {
-            const float* p = J.src + row * J.ld + c0;
-            if (c0 + 8 <= J.cols && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
-                const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (c0 + e < J.cols) v[e] = p[e];
+        for (int i = 0; i < 4; ++i) {
+            const int r = (t >> 3) + 32 * i;
+            const int64_t row = rb * 128 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < J.rows) {
+                const float* p = J.src + row * J.ld + cg;
+                if (cg + 4 <= J.cols && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+                    v = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (cg < J.cols) v.x = p[0];
+                    if (cg + 1 < J.cols) v.y = p[1];
+                    if (cg + 2 < J.cols) v.z = p[2];
+                    if (cg + 3 < J.cols) v.w = p[3];
+                }
             }
+            st[r][c] = v.x; st[r][c + 1] = v.y; st[r][c + 2] = v.z; st[r][c + 3] = v.w;
         }
     }
-    uint4* o = J.out + tile * kTileOf<false> + kc * 128 + r;
-    uint2 h0, m0, l0, h1, m1, l1;
-    split4(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
-    split4(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);
-    o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-    o[4 * 128] = make_uint4(m0.x, m0.y, m1.x, m1.y);
-    o[8 * 128] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int id = t + 256 * h, r = id & 127, kc = id >> 7;
+        const float* v = &st[r][kc * 8];
+        uint4* o = J.out + tile * kTileOf<false> + kc * 128 + r;
+        uint2 h0, m0, l0, h1, m1, l1;
+        split4(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
+        split4(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);
+        o[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        o[4 * 128] = make_uint4(m0.x, m0.y, m1.x, m1.y);
+        o[8 * 128] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
 }
 
 // Row producers that write the f16x2 image of a GEMM operand directly, in one pass over the rows: a
@@ -898,7 +913,7 @@ extern "C" int hd_limb_pack_multi_f32(const hd_pack_job* jobs, int n_jobs, void*
         o.nslab = (int)((lcols + 31) / 32);
         o.trans = j.transposed ? 1 : 0;
         o.block0 = (unsigned)blocks;
-        blocks += (uint64_t)((lrows + 127) / 128) * o.nslab * 2;           // 512 chunks per tile and slab = 2 blocks
+        blocks += (uint64_t)((lrows + 127) / 128) * o.nslab;               // one workgroup per tile and slab (512 chunks)
         HD_REQUIRE(blocks < (1ULL << 31), "hd_limb_pack_multi_f32: too many workgroups");
     }
     if (pj.n == 0) return HD_OK;
