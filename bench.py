@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0
 GEMM_PEAKS = {"mlp_chain": MFMA_BF16_PEAK_TFLOPS / 6, "gemm_limbs": MFMA_BF16_PEAK_TFLOPS / 6, "gemm_f32_bf16x3": MFMA_BF16_PEAK_TFLOPS / 6,
               "gemm_f16x2": MFMA_BF16_PEAK_TFLOPS / 3, "gemm_f32_mfma": MFMA_F32_PEAK_TFLOPS}
 # kernel-name prefixes in the rocprofv3 PMC summary (the two limb formats are instantiations of one template)
-GEMM_PMC_KEYS = {"mlp_chain": "mlp_chain", "gemm_limbs": "gemm_limbs<64, 4, false", "gemm_f32_bf16x3": "gemm_f32_bf16x3",
+GEMM_PMC_KEYS = {"mlp_chain": "mlp_chain", "gemm_limbs": "gemm_limbs", "gemm_f32_bf16x3": "gemm_f32_bf16x3",
                  "gemm_f16x2": "gemm_limbs<128, 8, true", "gemm_f32_mfma": "gemm_f32_mfma"}
 PEAK_NOTES = {"mlp_chain": "dense bf16 MFMA peak 2500 TFLOP/s / 6 bf16 MFMAs per algorithmic fp32 product (the five denoiser "
                            "layers as ONE persistent launch, csrc/gemm_chain.hip)",

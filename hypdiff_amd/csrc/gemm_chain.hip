@@ -217,7 +217,7 @@ __device__ __forceinline__ bool dep_ready(const ChainArgs& P, const int* tab, in
 #ifndef HD_CHAIN_EXPERIMENT
 #define HD_CHAIN_EXPERIMENT 0      // timing experiments only (results are wrong): 1 = two staging pieces of nine,
 #endif                             // 2 = 8 MFMAs of 48, 3 = 6 fragment reads of 18
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void mlp_chain(const ChainArgs P) {
+__device__ __forceinline__ void mlp_chain_body(const ChainArgs& P) {
     __shared__ uint4 lds[CH_BUF];
     __shared__ int nxt_s[8];                                  // successor: {queue, index, ready, layer, row block, column tile}
     __shared__ int tab[TAB_SIZE];
@@ -724,6 +724,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     }
 }
 
+// The launch of a whole stack, and the same body under a second name for a chain of ONE layer (a single GEMM over many
+// rows, ops.gemm_limbs: HypLinear's 512 x 512 in the bench step): two kernels in a rocprofv3 trace, so that the average
+// duration and the counters of the five-layer launch are its own.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void mlp_chain(const ChainArgs P) { mlp_chain_body(P); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_limbs_wide(const ChainArgs P) { mlp_chain_body(P); }
+
 }  // namespace
 
 extern "C" int64_t hd_mlp_chain_workspace_bytes(int64_t rows, int n_layers) {
@@ -842,13 +848,18 @@ extern "C" int hd_mlp_chain_limbs_f32(const void* A0, int64_t rows, const hd_mlp
     }
     if (!attr_set[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                100 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_limbs_wide), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 100 * 1024) != hipSuccess) {
             set_error("hd_mlp_chain_limbs_f32: hipFuncSetAttribute failed");
             return HD_EHIP;
         }
         attr_set[dev] = true;
     }
-    mlp_chain<<<dim3((unsigned)grid), dim3(256), pad, (hipStream_t)st>>>(P);
+    if (n_layers == 1)
+        gemm_limbs_wide<<<dim3((unsigned)grid), dim3(256), pad, (hipStream_t)st>>>(P);
+    else
+        mlp_chain<<<dim3((unsigned)grid), dim3(256), pad, (hipStream_t)st>>>(P);
     return check_launch("hd_mlp_chain_limbs_f32");
 }
 
