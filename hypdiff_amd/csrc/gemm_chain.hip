@@ -58,6 +58,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -216,7 +217,10 @@ __device__ __forceinline__ bool dep_ready(const ChainArgs& P, const int* tab, in
 #endif
 #ifndef HD_CHAIN_EXPERIMENT
 #define HD_CHAIN_EXPERIMENT 0      // timing experiments only (results are wrong): 1 = two staging pieces of nine,
-#endif                             // 2 = 8 MFMAs of 48, 3 = 6 fragment reads of 18
+#endif                             // 2 = 8 MFMAs of 48, 3 = 6 fragment reads of 18, 4 = the multiplies as 48 v_mfma_f32_32x32x16_bf16
+                                   // (4, measured on one box against the kernel as it is: 551-569 against 454-467 us per chain, with one
+                                   // accumulator after the other as with the four in turn -- the 32-row shape, half as many instructions of
+                                   // twice the length for the same fragments, is a fifth SLOWER here, so the 16x16x32 form stays)
 __device__ __forceinline__ void mlp_chain_body(const ChainArgs& P) {
     __shared__ uint4 lds[CH_BUF];
     __shared__ int nxt_s[8];                                  // successor: {queue, index, ready, layer, row block, column tile}
@@ -352,6 +356,15 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& P) {
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+#if HD_CHAIN_EXPERIMENT == 4
+            f32x16 acc16[2][2];                                // timing only: the slab's multiplies as 48 x 32x32x16 (wrong results)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc16[i][j][r] = 0.f;
+#endif
             // successor, fetched asynchronously by thread 0 while this tile multiplies (nslab >= 4)
             // thread 0 only.  `pend` is the ONE register that receives what the op issued in the previous slab returns;
             // it is read at the start of the next slab's step, after the vmcnt(0) at the top of that slab, so the compiler
@@ -491,8 +504,18 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& P) {
                 HD_MM(0, 0)                                                                                      \
                 acc[i][j] = c;                                                                                   \
             }
+#if HD_CHAIN_EXPERIMENT == 4
+#define HD_MM32(ks, wl, al) _Pragma("unroll") for (int I = 0; I < 2; ++I) _Pragma("unroll") for (int J = 0; J < 2; ++J)        \
+        acc16[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[2 * J + ks][wl]),                \
+                                                              __builtin_bit_cast(bf16x8, fa[2 * I + ks][al]), acc16[I][J], 0, 0, 0);
+                // the four accumulators in turn: no multiply waits for the one before it
+                HD_MM32(0, 0, 2) HD_MM32(0, 2, 0) HD_MM32(0, 1, 1) HD_MM32(0, 0, 1) HD_MM32(0, 1, 0) HD_MM32(0, 0, 0)
+                HD_MM32(1, 0, 2) HD_MM32(1, 2, 0) HD_MM32(1, 1, 1) HD_MM32(1, 0, 1) HD_MM32(1, 1, 0) HD_MM32(1, 0, 0)
+#undef HD_MM32
+#else
                 HD_MMS(0, 2)
                 if (NJ == 4 && !narrow) { HD_MMS(2, NJ) }
+#endif
                 if (HD_CHAIN_PRIO == 2) __builtin_amdgcn_s_setprio(0);
 #undef HD_MMS
 #undef HD_MM
@@ -564,7 +587,11 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& P) {
                             const int nb = nq + j * 16 + 4 * kq;
                             float x[4];
 #pragma unroll
+#if HD_CHAIN_EXPERIMENT == 4
+                            for (int e = 0; e < 4; ++e) x[e] = acc16[i >> 1][(2 * jp + j) >> 1][((i & 1) * 2 + ((2 * jp + j) & 1)) * 4 + e] + bq[j][e];
+#else
                             for (int e = 0; e < 4; ++e) x[e] = acc[i][2 * jp + j][e] + bq[j][e];
+#endif
                             if (Z && row_ok) {                  // training: the pre-activation is kept for the backward pass
                                 float* zo = Z + (size_t)m * ldc + nb;
                                 if (vec && nb + 3 < N) {
