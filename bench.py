@@ -235,7 +235,13 @@ def one_step(w, t, ev=None, i=0):
         h = w["enc"].encode(be["x"], be["adj"])
     pred, x0 = w["diff"].p_sample(bd["img"], None, 1, bd["direction"], bd["labels"], bd["u0"], t, None, True)
     main.wait_stream(side)
-    h.record_stream(main)
+    # No h.record_stream(main): the block of h (allocated in the side stream's pool) is handed back when the caller drops
+    # h, and whatever the side stream allocates next is enqueued behind the next step's side.wait_stream(main), i.e.
+    # behind every use of h on the main stream that was issued before the drop -- the ordering record_stream would
+    # enforce with events.  With record_stream the allocator may reuse a freed h only once an event on the main stream has
+    # COMPLETED; the host runs tens of steps ahead of the GPU, so every step in flight took a fresh 32 MB block: 28
+    # hipMalloc calls and 0.9 GB more reserved memory over the first 80 pipelined steps, which was the "settling" of the
+    # two-stream arrangement (0.68 ms at step 10, 0.63 from step 50 on; tools/probes/two_stream_ramp.py).
     return h, pred
 
 

@@ -24,10 +24,15 @@ with torch.no_grad():
     w["side_stream"] = side0 if early else torch.cuda.Stream()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     ev[0].record()
+    mallocs = []
     for i in range(steps):
         bench.one_step(w, 500 - (i % 400), None, i)
         ev[i + 1].record()
+        st = torch.cuda.memory_stats()
+        mallocs.append((st.get("num_device_alloc", 0), st.get("reserved_bytes.all.current", 0) >> 20))
     torch.cuda.synchronize()
 d = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
 for a in range(0, steps, 10):
     print(f"steps {a:3d}-{a + 9:3d}: " + " ".join(f"{v:.3f}" for v in d[a:a + 10]), flush=True)
+print("device allocations (count, reserved MiB) after steps 0, 1, 2, 5, 10, 20, 40, last:",
+      [mallocs[i] for i in (0, 1, 2, 5, 10, 20, 40, steps - 1) if i < steps])
