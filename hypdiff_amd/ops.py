@@ -534,7 +534,8 @@ def linear_chain(x, layers):
 # ---- the whole stack as ONE persistent launch over many rows (csrc/gemm_chain.hip) ----
 MLP_CHAIN_MIN_ROWS = 4096                                     # below this the per-layer launches are not round-bound
 _NO_MLP_CHAIN = bool(os.environ.get("HD_NO_MLP_CHAIN"))       # A/B knob: one hd_gemm_limbs_f32 launch per layer
-GEMM_VIA_CHAIN = os.environ.get("HD_GEMM_VIA_CHAIN", "1") != "0"   # a single limb GEMM over many rows as a chain of one layer
+GEMM_VIA_CHAIN = os.environ.get("HD_GEMM_VIA_CHAIN", "0") != "0"   # a single limb GEMM over many rows as a chain of one layer
+# (same bits; measured neutral in the bench step: 0.6414-0.6421 against 0.6419-0.6425 ms on one stream, so the plain launch stays)
 _mlp_chain_ws = {}
 
 
