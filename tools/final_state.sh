@@ -1,3 +1,6 @@
+#!/bin/bash
+# The round-end measurement set on one box: GPU suite with the margin table, smoke, bench (defaults and the driver's flags),
+# rocprofv3 kernel stats, PMC traffic.  gpurun -- bash tools/final_state.sh
 set -e
 cd $GRAFT_REPO_ROOT
 bash tools/parity_margin.sh
