@@ -47,10 +47,11 @@ class BaseModel(nn.Module):
             if (not torch.is_grad_enabled() and hit is not None and hit[0]() is x
                     and hit[1] == (x._version, x.data_ptr())):
                 x = hit[2]
+                ops._ready(hit[3])
             else:
                 src, x = x, torch.cat([torch.zeros_like(x)[:, 0:1], x], dim=1)
                 if not torch.is_grad_enabled() and x.shape[1] >= ops.SPARSE_ROWS_MIN_WIDTH:
-                    self._time_col_cache = (weakref.ref(src), (src._version, src.data_ptr()), x)
+                    self._time_col_cache = (weakref.ref(src), (src._version, src.data_ptr()), x, ops._tag())
         h = self.encoder.encode(x, adj)
         return h, 1, h, adj
 

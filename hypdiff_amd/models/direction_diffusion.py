@@ -143,7 +143,9 @@ class mlp(nn.Module):
         w = self.fc1.weight
         key = (w.data_ptr(), w._version, ld)
         if self._w1_cache is None or self._w1_cache[0] != key:
-            self._w1_cache = (key, ops._pad_k(w.detach(), ld))
+            self._w1_cache = (key, ops._pad_k(w.detach(), ld), ops._tag())
+        else:
+            ops._ready(self._w1_cache[2])              # filled on another stream: wait for it (ops._tag)
         return self._w1_cache[1]
 
     def forward(self, x, t):
@@ -284,7 +286,9 @@ class diffusion(nn.Module):
         if self._sign_cache is None or self._sign_cache[0] != key:
             # the cache keeps the direction tensors alive, so their ids cannot be reused
             self._sign_cache = (key, torch.sign(torch.stack(list(direction))).to(torch.float32).contiguous(),
-                                list(direction))
+                                list(direction), ops._tag())
+        else:
+            ops._ready(self._sign_cache[3])
         return self._sign_cache[1]
 
     def directions(self, u0):
@@ -295,12 +299,13 @@ class diffusion(nn.Module):
             key = (id(u0), u0._version, u0.data_ptr())
             hit = getattr(self, "_dir_cache", None)
             if hit is not None and hit[0] == key and hit[2]() is u0:
+                ops._ready(hit[3])
                 return hit[1]
         d = self.manifold.logmap0(u0 if torch.is_tensor(u0) else torch.stack(list(u0)), c=1.0)
         out = list(d.unbind(0))
         if torch.is_tensor(u0):
             import weakref
-            self._dir_cache = (key, out, weakref.ref(u0))
+            self._dir_cache = (key, out, weakref.ref(u0), ops._tag())
         return out
 
     def _t_frac(self, t):
@@ -317,11 +322,12 @@ class diffusion(nn.Module):
             key = (id(u0), u0._version, u0.data_ptr())
             hit = getattr(self, "_c64_cache", None)
             if hit is not None and hit[0] == key and hit[2]() is u0:
+                ops._ready(hit[3])
                 return hit[1]
         c = (u0 if torch.is_tensor(u0) else torch.stack(list(u0))).to(torch.float64).contiguous()
         if torch.is_tensor(u0):
             import weakref
-            self._c64_cache = (key, c, weakref.ref(u0))
+            self._c64_cache = (key, c, weakref.ref(u0), ops._tag())
         return c
 
     def tran_direction(self, direction_vector, gaussian_point, labels):

@@ -70,7 +70,9 @@ class diffusionset(dd.diffusion):
         key = tuple((id(d), d._version) for d in direction)
         if self._sign_cache is None or self._sign_cache[0] != key:
             tab = torch.cat([d.reshape(-1, d.shape[-1]) for d in direction], 0)
-            self._sign_cache = (key, torch.sign(tab).to(torch.float32).contiguous(), list(direction))
+            self._sign_cache = (key, torch.sign(tab).to(torch.float32).contiguous(), list(direction), ops._tag())
+        else:
+            ops._ready(self._sign_cache[3])
         return self._sign_cache[1]
 
     def directions(self, u0):

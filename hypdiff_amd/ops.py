@@ -207,6 +207,27 @@ def _pad_k(t, k_pad):
     return out
 
 
+# Cached device buffers (padded / transposed / limb-split weights, sparse feature rows) are filled by kernels on the stream
+# that was current at the miss.  A hit on ANOTHER stream must not read them before those kernels have finished: every entry
+# carries (stream, event recorded behind the fill), and a hit from a different stream waits for the event unless it has
+# completed (the common case: one query, no wait).
+def _tag():
+    if not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+        return None
+    st = torch.cuda.current_stream()
+    ev = torch.cuda.Event()
+    ev.record(st)
+    return (st.cuda_stream, ev)
+
+
+def _ready(tag):
+    if tag is None:
+        return
+    st = torch.cuda.current_stream()
+    if st.cuda_stream != tag[0] and not torch.cuda.is_current_stream_capturing() and not tag[1].query():
+        st.wait_event(tag[1])
+
+
 _pad_cache = {}
 
 
@@ -217,11 +238,12 @@ def pad_k_cached(t, k_pad):
         return t
     hit = _pad_cache.get(id(t))
     if hit is not None and hit[0]() is t and hit[1] == (t._version, t.data_ptr(), k_pad):
+        _ready(hit[3])
         return hit[2]
     out = _pad_k(t.detach(), k_pad)
     if len(_pad_cache) > 64:
         _pad_cache.clear()
-    _pad_cache[id(t)] = (weakref.ref(t), (t._version, t.data_ptr(), k_pad), out)
+    _pad_cache[id(t)] = (weakref.ref(t), (t._version, t.data_ptr(), k_pad), out, _tag() if out.is_cuda else None)
     return out
 
 
@@ -232,11 +254,12 @@ def transposed_cached(w):
     """w^T as a contiguous tensor, rebuilt when the parameter changes (keyed like pad_k_cached)."""
     hit = _wt_cache.get(id(w))
     if hit is not None and hit[0]() is w and hit[1] == (w._version, w.data_ptr()):
+        _ready(hit[3])
         return hit[2]
     out = w.detach().t().contiguous()
     if len(_wt_cache) > 64:
         _wt_cache.clear()
-    _wt_cache[id(w)] = (weakref.ref(w), (w._version, w.data_ptr()), out)
+    _wt_cache[id(w)] = (weakref.ref(w), (w._version, w.data_ptr()), out, _tag() if out.is_cuda else None)
     return out
 
 
@@ -245,6 +268,7 @@ def smallk_image_cached(w):
     key = ("smallk", id(w))
     hit = _wt_cache.get(key)
     if hit is not None and hit[0]() is w and hit[1] == (w._version, w.data_ptr()):
+        _ready(hit[3])
         return hit[2]
     wd = w.detach()
     if wd.stride(1) != 1:
@@ -253,7 +277,7 @@ def smallk_image_cached(w):
     _lib.call("hd_smallk_pack_w_f32", _p(wd), wd.stride(0), wd.shape[0], wd.shape[1], _p(img), _stream())
     if len(_wt_cache) > 64:
         _wt_cache.clear()
-    _wt_cache[key] = (weakref.ref(w), (w._version, w.data_ptr()), img)
+    _wt_cache[key] = (weakref.ref(w), (w._version, w.data_ptr()), img, _tag())
     return img
 
 
@@ -380,16 +404,17 @@ def weight_limbs(w, fmt="bf16x3", need_norm=False):
     hit = _wlimb_cache.get(key)
     if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == w.data_ptr():
         img, wn = hit[3]
+        _ready(hit[4])
         if need_norm and wn is None:
             wn = float(w.detach().double().norm(dim=1).max())
-            _wlimb_cache[key] = hit[:3] + ((img, wn),)
+            _wlimb_cache[key] = hit[:3] + ((img, wn), hit[4])
         return img, wn
     wd = w.detach()
     img = limb_pack(wd if wd.stride(1) == 1 else wd.contiguous(), fmt)
     wn = float(wd.double().norm(dim=1).max()) if need_norm else None
     if len(_wlimb_cache) > 256:
         _wlimb_cache.clear()
-    _wlimb_cache[key] = (weakref.ref(w), w._version, w.data_ptr(), (img, wn))
+    _wlimb_cache[key] = (weakref.ref(w), w._version, w.data_ptr(), (img, wn), _tag())
     return img, wn
 
 
@@ -647,6 +672,7 @@ def chain_image_cached(w):
     key = ("chain", id(w))
     hit = _wt_cache.get(key)
     if hit is not None and hit[0]() is w and hit[1] == (w._version, w.data_ptr()):
+        _ready(hit[3])
         return hit[2]
     wd = w.detach()
     if wd.stride(1) != 1:
@@ -655,7 +681,7 @@ def chain_image_cached(w):
     _lib.call("hd_chain_pack_w_f32", _p(wd), wd.stride(0), wd.shape[0], wd.shape[1], _p(img), _stream())
     if len(_wt_cache) > 256:
         _wt_cache.clear()
-    _wt_cache[key] = (weakref.ref(w), (w._version, w.data_ptr()), img)
+    _wt_cache[key] = (weakref.ref(w), (w._version, w.data_ptr()), img, _tag())
     return img
 
 
@@ -836,6 +862,7 @@ def sparse_rows_cached(x, manifold, c, lift):
     key = (id(x), manifold.abi, cv.c)
     hit = _sparse_rows_cache.get(key)
     if hit is not None and hit[0]() is x and hit[1] == (x._version, x.data_ptr()):
+        _ready(hit[3])
         return hit[2]
     res = None
     if int(torch.count_nonzero(x)) <= SPARSE_ROWS_MAX_PER_ROW * x.shape[0]:
@@ -854,7 +881,7 @@ def sparse_rows_cached(x, manifold, c, lift):
             res = SparseRows(CSR(rowptr, col, val, tuple(u.shape)), xn, tuple(u.shape), manifold.abi)
     if len(_sparse_rows_cache) > 16:
         _sparse_rows_cache.clear()
-    _sparse_rows_cache[key] = (weakref.ref(x), (x._version, x.data_ptr()), res)
+    _sparse_rows_cache[key] = (weakref.ref(x), (x._version, x.data_ptr()), res, _tag() if x.is_cuda else None)
     return res
 
 

@@ -216,3 +216,27 @@ def test_single_gemm_as_a_chain_of_one_layer(shape, monkeypatch):
         if limbs:
             assert torch.equal(ops.limb_unpack(l0), ops.limb_unpack(l1))
     assert not ops.mlp_chain_failed()
+
+
+@pytest.mark.gpu
+def test_cached_weight_image_built_on_another_stream_is_awaited():
+    """ops.weight_limbs / pad_k_cached fill their cached buffers on the stream that was current at the miss.  A hit on
+    another stream right afterwards must wait for that fill (ops._tag / ops._ready): here the fill sits behind ~20 ms of
+    busy-waiting on a side stream, and the main stream unpacks the image at once."""
+    from hypdiff_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(900, 802, generator=g).to(dev)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(40_000_000)
+        img_side, _ = ops.weight_limbs(w)
+        pad_side = ops.pad_k_cached(w, 804)
+    img_main, _ = ops.weight_limbs(w)                     # hits while the side stream is still asleep
+    pad_main = ops.pad_k_cached(w, 804)
+    assert img_main is img_side and pad_main is pad_side
+    back = ops.limb_unpack(img_main)                      # main stream
+    cols = pad_main[:, :802].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(back, w) and torch.equal(cols, w)
