@@ -217,6 +217,13 @@ def one_step(w, t, ev=None, i=0):
     p_sample advances the latents of batch (i + 1) % 2 on the main stream; joined before the step returns."""
     side = w.get("side_stream")
     if side is None:
+        idle = w.get("idle_side_stream")
+        if idle is not None:
+            # the side stream of the pipelined legs exists already: one 4 KB kernel per step keeps its hardware queue live
+            # (a caller that pipelines has it live all along).  A queue that first becomes active when the pipelined steps
+            # start costs them 5-10 % for their first ~12 steps (tools/probes/two_stream_ramp.py: 0.70-0.73 against 0.66 ms)
+            with torch.cuda.stream(idle):
+                w["tick"].add_(1)
         if ev is not None:
             e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             e[0].record()
@@ -526,6 +533,9 @@ def main():
     ap.add_argument("--one-stream", action="store_true",
                     help="headline with both phases of a step on ONE HIP stream (default: software pipeline across two "
                          "batches on two streams, joined per step)")
+    ap.add_argument("--no-side-keepalive", action="store_true",
+                    help="the one-stream leg ahead of a pipelined headline leaves the side stream untouched (default: one "
+                         "4 KB kernel per step on it, so that its hardware queue is live when the pipelined steps start)")
     ap.add_argument("--no-overlap-leg", action="store_true",
                     help="skip the secondary leg that repeats the steps with the other stream arrangement")
     ap.add_argument("--no-exact-leg", action="store_true", help="skip the comparison legs on the other fp32 GEMM kernels")
@@ -599,6 +609,8 @@ def main():
         # takes to leave its idle clocks, and whichever leg came first measured 8-10 % slow in short runs.
         if side is None:
             w["side_stream"] = torch.cuda.Stream()
+        elif not a.no_side_keepalive:
+            w["idle_side_stream"], w["tick"] = side, torch.zeros(1024, device=device)
         try:
             k3 = max(a.steps, 100)                     # its own step count: at least 100, i.e. >= 70 ms of load
             w3 = min(a.warmup, 3)
@@ -611,6 +623,7 @@ def main():
                                "pipeline gets") + "; run before the headline steps (first on the idle chip)"})
         finally:
             w.pop("side_stream", None)
+            w.pop("idle_side_stream", None)
     progress("secondary stream-arrangement leg done")
     if side is not None:
         w["side_stream"] = side
@@ -671,8 +684,12 @@ def main():
                    "priming_steps": 0,
                    **({"rehearsal": "HD_BENCH_SHARE_GPU=1: all %d ranks share cuda:0 over backend %s; exercises the N-rank "
                                     "code path only, NOT a scaling measurement" % (world, a.backend)} if share and world > 1 else {}),
-                   "order": ("secondary leg in the other stream arrangement (%d untimed-for-the-headline steps), then "
-                             % (untimed_before - a.warmup) if other else "") +
+                   "side_queue_keepalive": bool(other and side is not None and not a.no_side_keepalive),
+                   "order": ("secondary leg in the other stream arrangement (%d untimed-for-the-headline steps%s), then "
+                             % (untimed_before - a.warmup,
+                                "; each of them also launches one 4 KB kernel on the side stream of the pipelined legs, so that "
+                                "its hardware queue is live when they start" if side is not None and not a.no_side_keepalive
+                                else "") if other else "") +
                             "W warm-up + K timed headline steps, then the instrumented per-kernel pass, then the other legs; "
                             "warmup_effective = every step issued before the K timed ones"},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,

@@ -12,13 +12,18 @@ import bench  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 80
 w = bench.build_workload(512, 1000, 1432, "cuda:0")
-early = len(sys.argv) > 2 and sys.argv[2] == "early"      # create the side stream (and touch it) before the one-stream steps
+early = len(sys.argv) > 2 and sys.argv[2] in ("early", "keepalive")   # create the side stream (and touch it) before the one-stream steps
+keepalive = len(sys.argv) > 2 and sys.argv[2] == "keepalive"           # ... and launch a tiny kernel on it in every one-stream step
 if early:
     side0 = torch.cuda.Stream()
     with torch.cuda.stream(side0):
         torch.zeros(1024, device="cuda:0").add_(1)
 with torch.no_grad():
+    tiny = torch.zeros(1024, device="cuda:0")
     for i in range(100):
+        if keepalive:
+            with torch.cuda.stream(side0):
+                tiny.add_(1)
         bench.one_step(w, 500 - (i % 400), None, i)
     torch.cuda.synchronize()
     w["side_stream"] = side0 if early else torch.cuda.Stream()
