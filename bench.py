@@ -19,6 +19,11 @@ N > 1: when WORLD_SIZE is not set this process is only a LAUNCHER -- it touches 
 non-zero if any rank does.  Under torch.distributed.run (WORLD_SIZE set) it is a rank.  Each rank owns its own
 graph-set shard of the same size (weak scaling, no data-path collective in the step).
 `--dry --backend gloo`: the launcher / rendezvous / JSON merge without a GPU or a kernel (tests/test_bench_launcher.py).
+The one-stream leg that runs ahead of a pipelined headline launches one 4 KB kernel per step on the side stream, so that its
+hardware queue is live when the pipelined steps start (`config.side_queue_keepalive`; `--no-side-keepalive`).
+More than one rank: a secondary leg that stops cannot cost the line (`--legs-timeout`).  HD_BENCH_SHARE_GPU=1 with
+`--backend gloo`: every rank on cuda:0, collectives staged through the host -- a rehearsal of the N-rank path on a one-GPU
+box, flagged in `config.rehearsal`, never a scaling figure.  HD_BENCH_VERBOSE=1: a progress line per leg and rank on stderr.
 """
 import argparse
 import json
