@@ -240,3 +240,39 @@ def test_cached_weight_image_built_on_another_stream_is_awaited():
     cols = pad_main[:, :802].clone()
     torch.cuda.synchronize()
     assert torch.equal(back, w) and torch.equal(cols, w)
+
+
+@pytest.mark.gpu
+def test_weight_gradients_in_one_launch_edge_cases():
+    """hd_gemm_tn_limbs_multi_f32: no rows -> zero gradients (as hd_gemm_tn_limbs_f32 and an empty torch sum); a single
+    job; more than 8 jobs, no jobs and a misaligned workspace are refused with a message, nothing is launched."""
+    from hypdiff_amd import _lib, autograd as ag, ops
+    dev = "cuda:0"
+    # R = 0: images of zero rows
+    a0 = ops.limb_pack(torch.zeros(0, 72, device=dev), "bf16x3")
+    b0 = ops.limb_pack(torch.zeros(0, 40, device=dev), "bf16x3")
+    out = torch.full((72, 40), 7.0, device=dev)
+    cs = torch.full((72,), 7.0, device=dev)
+    (w, c), = ag.gemm_tn_limbs_multi([(a0, b0, out, cs)])
+    torch.cuda.synchronize()
+    assert w.data_ptr() == out.data_ptr() and float(w.abs().max()) == 0.0 and float(c.abs().max()) == 0.0
+    # one job = the single entry point
+    g = torch.Generator().manual_seed(1)
+    a = ops.limb_pack(torch.randn(300, 72, generator=g).to(dev), "bf16x3")
+    b = ops.limb_pack(torch.randn(300, 40, generator=g).to(dev), "bf16x3")
+    (w1, c1), = ag.gemm_tn_limbs_multi([(a, b, None, None)])
+    w0, c0 = ag.gemm_tn_limbs(a, b)
+    assert torch.equal(w0, w1) and torch.equal(c0, c1)
+    # refused calls
+    job = _lib.HdTnJob(ops._p(a.buf), ops._p(b.buf), ops._p(w1), ops._p(c1), 72, 40, 40)
+    nine = (_lib.HdTnJob * 9)(*([job] * 9))
+    assert _lib.load().hd_gemm_tn_limbs_multi_workspace_floats(300, nine, 9) == -1
+    ws = torch.zeros(1 << 20, device=dev)
+    for arr, n, wsp in ((nine, 9, ops._p(ws)), (nine, 0, ops._p(ws))):
+        with pytest.raises(RuntimeError, match="between 1 and 8 jobs"):
+            _lib.call("hd_gemm_tn_limbs_multi_f32", 300, arr, n, wsp, ops._stream())
+    with pytest.raises(RuntimeError, match="misaligned workspace"):
+        _lib.call("hd_gemm_tn_limbs_multi_f32", 300, nine, 1, ops._p(ws[1:]), ops._stream())
+    bad = _lib.HdTnJob(ops._p(a.buf), ops._p(b.buf), ops._p(w1), ops._p(c1), 70, 40, 40)      # P not a multiple of 4
+    with pytest.raises(RuntimeError, match="multiples of 4"):
+        _lib.call("hd_gemm_tn_limbs_multi_f32", 300, (_lib.HdTnJob * 1)(bad), 1, ops._p(ws), ops._stream())
