@@ -217,10 +217,12 @@ __device__ __forceinline__ bool dep_ready(const ChainArgs& P, const int* tab, in
 #endif
 #ifndef HD_CHAIN_EXPERIMENT
 #define HD_CHAIN_EXPERIMENT 0      // timing experiments only (results are wrong): 1 = two staging pieces of nine,
-#endif                             // 2 = 8 MFMAs of 48, 3 = 6 fragment reads of 18, 4 = the multiplies as 48 v_mfma_f32_32x32x16_bf16
+#endif                             // 2 = 8 MFMAs of 48, 3 = 6 fragment reads of 18, 4 = the multiplies as 48 v_mfma_f32_32x32x16_bf16, 5 = four of the six A pieces (the bytes of an fp32 A operand)
                                    // (4, measured on one box against the kernel as it is: 551-569 against 454-467 us per chain, with one
                                    // accumulator after the other as with the four in turn -- the 32-row shape, half as many instructions of
                                    // twice the length for the same fragments, is a fifth SLOWER here, so the 16x16x32 form stays)
+                                   // (5, same way: 440-447 against 453-459 us -- a sixth fewer staged bytes buy 2-4 % at most, before the
+                                   // VALU work of splitting an fp32 A operand in registers is paid: not pursued)
 __device__ __forceinline__ void mlp_chain_body(const ChainArgs& P) {
     __shared__ uint4 lds[CH_BUF];
     __shared__ int nxt_s[8];                                  // successor: {queue, index, ready, layer, row block, column tile}
@@ -316,6 +318,7 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& P) {
         const uint4* wsrc = (ws_) + (size_t)(t) * kTile;                                    \
         _Pragma("unroll") for (int q = 0; q < QA; ++q) {                                    \
             if (HD_CHAIN_EXPERIMENT == 1 && q) continue;                                    \
+            if (HD_CHAIN_EXPERIMENT == 5 && q >= 4) continue;                               \
             const int piece = q * 4 + wave;                                                 \
             glds16(as + piece * 64, lds + piece * 64);                                      \
         }                                                                                   \
