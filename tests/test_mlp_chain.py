@@ -276,3 +276,17 @@ def test_weight_gradients_in_one_launch_edge_cases():
     bad = _lib.HdTnJob(ops._p(a.buf), ops._p(b.buf), ops._p(w1), ops._p(c1), 70, 40, 40)      # P not a multiple of 4
     with pytest.raises(RuntimeError, match="multiples of 4"):
         _lib.call("hd_gemm_tn_limbs_multi_f32", 300, (_lib.HdTnJob * 1)(bad), 1, ops._p(ws), ops._stream())
+
+
+@pytest.mark.gpu
+def test_chain_gang_order_gives_the_same_bits():
+    """HD_MLP_CHAIN_GANG hands the row blocks of a queue out in another order (gangs of G, column tile by column tile);
+    the order must not change a bit.  The knob is read when the library is first used, so the check runs in a process of
+    its own (tools/probes/chain_gang.py ... check: G = 2, 3, 5, 16 against G = 1 at the bench's shapes)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "probes", "chain_gang.py"), "2,3,5,16", "check"],
+                       capture_output=True, text=True, timeout=150)
+    assert r.returncode == 0 and "bit-identical" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
