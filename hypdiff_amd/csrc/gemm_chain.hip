@@ -69,7 +69,7 @@ constexpr int NJ = BNT / 32;                     // 16-column accumulators per w
 constexpr int CH_A = 4 * 3 * 128, CH_W = 4 * 3 * BNT, CH_BUF = CH_A + CH_W;
 constexpr int QA = 6, QW = 6;                    // 1 KiB LDS-DMA pieces per wavefront and slab (narrow tile: W pieces of two wavefronts only)
 // workspace words (unsigned): queue head q at q * 32 (a 128-byte line each), then fail, exited, then the counters
-constexpr int WS_FAIL = 256, WS_EXITED = 257, WS_STAT = 260, WS_EXIT_GROUP = 288, WS_DONE = 288 + 256;   // WS_STAT..+3: slow paths, polls that failed (flag 8)
+constexpr int WS_FAIL = 256, WS_EXITED = 257, WS_REPORT = 258, WS_STAT = 260, WS_EXIT_GROUP = 288, WS_DONE = 288 + 256;   // WS_STAT..+3: slow paths, polls that failed (flag 8)
 constexpr uint64_t kTimeoutTicks = 200000000ull; // 2 s of the 100 MHz wall clock
 
 struct Layer {
@@ -458,7 +458,7 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& P) {
                 if (t == 0 && done_l >= 0) {
                     // the previous tile's image stores were complete in every wavefront at this slab's first barrier (each
                     // waited vmcnt(0) before it): raise its row block's counter
-                    if (tid == 0)
+                    if (tid == 0 && !((P.flags & 64) && done_l == 0 && done_rb == 0))   // 64: test knob, see the host side
                         __hip_atomic_fetch_add(ws + WS_DONE + done_l * tiles_m + done_rb, 1u, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
                     done_l = -1;
@@ -683,7 +683,7 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& P) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (tid == 0) {
-                    if (done_l >= 0)
+                    if (done_l >= 0 && !((P.flags & 64) && done_l == 0 && done_rb == 0))
                         __hip_atomic_fetch_add(ws + WS_DONE + done_l * tiles_m + done_rb, 1u, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
                     if (P.flags & 8) {
@@ -739,9 +739,12 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& P) {
     if (P.dbg && tid == 0) P.dbg[blockIdx.x * 8 + 7] = ((unsigned long long)seq << 8) | (unsigned)my_xcd;
     if (nxt_s[0]) {
         const int words = WS_DONE + (P.n_layers > 1 ? (P.n_layers - 1) * tiles_m : 0);
+        // the fail word is per launch (cleared here: the next launch on this workspace is clean); what hd_mlp_chain_failed
+        // reads is the report word, raised below and cleared only by that query
         for (int i = tid; i < words; i += 256)
-            if (i != WS_FAIL && !(i >= WS_STAT && i < WS_STAT + 4)) __hip_atomic_store(ws + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i != WS_REPORT && !(i >= WS_STAT && i < WS_STAT + 4)) __hip_atomic_store(ws + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (nxt_s[1]) {                                         // a wait timed out somewhere: make the failure loud
+            if (tid == 0) __hip_atomic_store(ws + WS_REPORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const Layer& Lz = P.L[P.n_layers - 1];
             if (Lz.out_f32)
                 for (size_t i = tid; i < (size_t)M * Lz.ldc; i += 256)
@@ -854,6 +857,9 @@ extern "C" int hd_mlp_chain_limbs_f32(const void* A0, int64_t rows, const hd_mlp
     HD_REQUIRE(items < (1LL << 30), "hd_mlp_chain_limbs_f32: too many tiles");
     P.delay_ticks = knobs.delay_ns / 10;
     P.flags = knobs.flags;
+    // test knob, read on every call: the tiles of (layer 0, row block 0) never report completion, so the tiles of layer 1 that
+    // wait for them run into the bound (tests/test_mlp_chain.py: the launch ends, its outputs are NaN, the next one is clean)
+    if (const char* e = getenv("HD_MLP_CHAIN_TEST_WITHHOLD")) P.flags |= atoi(e) ? 64 : 0;
     P.gang = knobs.gang >= 1 && knobs.gang <= 16 ? knobs.gang : 1;
     P.dbg = nullptr;
     if (knobs.reload)
@@ -898,10 +904,10 @@ extern "C" int hd_mlp_chain_limbs_f32(const void* A0, int64_t rows, const hd_mlp
 extern "C" int hd_mlp_chain_failed(void* workspace, void* st) {
     if (!workspace) return 0;
     unsigned flag = 0;
-    if (hipMemcpyAsync(&flag, (unsigned*)workspace + WS_FAIL, 4, hipMemcpyDeviceToHost, (hipStream_t)st) != hipSuccess) return -1;
+    if (hipMemcpyAsync(&flag, (unsigned*)workspace + WS_REPORT, 4, hipMemcpyDeviceToHost, (hipStream_t)st) != hipSuccess) return -1;
     if (hipStreamSynchronize((hipStream_t)st) != hipSuccess) return -1;
     if (flag) {
-        if (hipMemsetAsync((unsigned*)workspace + WS_FAIL, 0, 4, (hipStream_t)st) != hipSuccess) return -1;
+        if (hipMemsetAsync((unsigned*)workspace + WS_REPORT, 0, 4, (hipStream_t)st) != hipSuccess) return -1;
     }
     return flag ? 1 : 0;
 }

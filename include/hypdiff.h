@@ -368,8 +368,9 @@ int hd_gemm_limbs_f32(const void* A, const void* W, const void* bias, const void
  * two).  K of layer i must equal N of layer i - 1; at most 8 layers.  workspace: hd_mlp_chain_workspace_bytes(rows,
  * n_layers) bytes of device memory, 16-byte aligned, ZERO-FILLED ONCE by the caller when it is allocated and from then
  * on only passed to this function; private to the call while it runs (one workspace per stream).  Never synchronises.
- * Every device-side wait is bounded (2 s): after a time-out the last layer's fp32 output is filled with NaN and
- * hd_mlp_chain_failed(workspace, stream) -- which DOES synchronise the stream -- returns 1 once and clears the flag. */
+ * Every device-side wait is bounded (2 s): after a time-out the last layer's outputs of THAT launch are NaN (its fail
+ * word is cleared when the launch leaves: the next launch on the workspace is clean) and
+ * hd_mlp_chain_failed(workspace, stream) -- which DOES synchronise the stream -- returns 1 once and clears the report. */
 typedef struct hd_mlp_chain_layer {
     const void* W;
     const void* bias;

@@ -290,3 +290,37 @@ def test_chain_gang_order_gives_the_same_bits():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "probes", "chain_gang.py"), "2,3,5,16", "check"],
                        capture_output=True, text=True, timeout=150)
     assert r.returncode == 0 and "bit-identical" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_chain_timeout_poisons_its_own_launch_only():
+    """The bounded wait of hd_mlp_chain_limbs_f32, exercised: with HD_MLP_CHAIN_TEST_WITHHOLD=1 the tiles of (layer 0, row
+    block 0) never report completion, the tiles of layer 1 that need them run into the 2 s bound, the launch ends (no hang)
+    with NaN outputs, hd_mlp_chain_failed reports 1 exactly once -- and the NEXT launch on the same workspace, with no query
+    in between, is clean and bit-identical to a launch before the failure (the fail word is per launch)."""
+    import os
+    import time
+    from hypdiff_amd import ops
+    dev = "cuda:0"
+    dims = [72, 200, 136, 68]
+    layers = _layers(dims, 5, dev)
+    a = ops.limb_pack(torch.randn(4500, dims[0], generator=torch.Generator().manual_seed(2)).to(dev), "bf16x3")
+    good = ops.mlp_chain(a, layers)
+    torch.cuda.synchronize()
+    assert torch.isfinite(good).all() and not ops.mlp_chain_failed()
+    os.environ["HD_MLP_CHAIN_TEST_WITHHOLD"] = "1"
+    try:
+        t0 = time.perf_counter()
+        bad = ops.mlp_chain(a, layers)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        os.environ.pop("HD_MLP_CHAIN_TEST_WITHHOLD", None)
+    assert 1.5 < dt < 30.0, dt                                   # ended by the bound, not by luck and not by a hang
+    assert torch.isnan(bad).all()                                # the failure is loud
+    again = ops.mlp_chain(a, layers)                             # no query in between
+    torch.cuda.synchronize()
+    assert torch.equal(again, good)
+    assert ops.mlp_chain_failed()                                # reported once ...
+    assert not ops.mlp_chain_failed()                            # ... and cleared
+    assert torch.equal(ops.mlp_chain(a, layers), good)
