@@ -248,6 +248,7 @@ def _ready(tag):
 
 
 _pad_cache = {}
+_pad_seen = {}
 
 
 def pad_k_cached(t, k_pad):
@@ -260,9 +261,18 @@ def pad_k_cached(t, k_pad):
         _ready(hit[3])
         return hit[2]
     out = _pad_k(t.detach(), k_pad)
-    if len(_pad_cache) > 64:
-        _pad_cache.clear()
-    _pad_cache[id(t)] = (weakref.ref(t), (t._version, t.data_ptr(), k_pad), out, _tag() if out.is_cuda else None)
+    # An operand enters the cache at its SECOND miss as the same live object: the activations of inner layers come through
+    # here too (ops.gemm pads whatever it is given), are new tensors on every call and would only push the weights out
+    # (and pay for an event each: config 1's encode, 14-wide rows, is bound by the host)
+    seen = _pad_seen.get(id(t))
+    if seen is not None and seen() is t:
+        if len(_pad_cache) > 64:
+            _pad_cache.clear()
+        _pad_cache[id(t)] = (weakref.ref(t), (t._version, t.data_ptr(), k_pad), out, _tag() if out.is_cuda else None)
+    else:
+        if len(_pad_seen) > 256:
+            _pad_seen.clear()
+        _pad_seen[id(t)] = weakref.ref(t)
     return out
 
 

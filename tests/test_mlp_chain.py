@@ -228,6 +228,7 @@ def test_cached_weight_image_built_on_another_stream_is_awaited():
     g = torch.Generator().manual_seed(3)
     w = torch.randn(900, 802, generator=g).to(dev)
     side = torch.cuda.Stream()
+    ops.pad_k_cached(w, 804)                              # first sighting: a padded operand is cached at its second miss
     torch.cuda.synchronize()
     with torch.cuda.stream(side):
         torch.cuda._sleep(40_000_000)
