@@ -531,6 +531,16 @@ def wants_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
+def chain_wants_grad(chain, *tensors):
+    """wants_grad over the weights and biases of a [(weight, bias, epi), ...] list and further tensors.  The callers used
+    to pass *module.parameters(): a walk of the module tree, 25-60 us per call and several calls per step, paid in
+    inference too because the arguments are built before wants_grad can look at torch.is_grad_enabled()."""
+    if not torch.is_grad_enabled():
+        return False
+    return any(t is not None and t.requires_grad for t in tensors) or \
+        any((w is not None and w.requires_grad) or (b is not None and b.requires_grad) for w, b, _ in chain)
+
+
 # ---- encoder (HGCN / HNN) training: lp_train.py:66-82 --------------------------------------
 MAP_CODES = {"proj": 0, "expmap0": 1, "logmap0": 2, "expmap0_proj": 3}
 

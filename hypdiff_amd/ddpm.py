@@ -28,7 +28,7 @@ class MLP(nn.Module):
         ops._dev(x)
         x = x.to(torch.float32).contiguous()
         last = len(self.layers) - 1
-        if hag.wants_grad(x, *self.parameters()):
+        if hag.chain_wants_grad(self.chain(), x):
             # training (diff_graphset.py:64-75): HIP forward + backward, see hypdiff_amd/autograd.py
             if x.shape[1] % 4:
                 x = ops._pad_k(x, (x.shape[1] + 3) // 4 * 4)
@@ -57,10 +57,9 @@ class Backbone(nn.Module):
 
     def forward(self, x, idx):
         ops._dev(x)
-        params = (self.embedding_layer.weight, *self.linear_model1.parameters(), *self.linear_model2.parameters())
-        if not hag.wants_grad(x, *params):
+        c1, c2 = self.linear_model1.chain(), self.linear_model2.chain()
+        if not hag.chain_wants_grad(c1 + c2, x, self.embedding_layer.weight):
             xf = x.to(torch.float32)
-            c1, c2 = self.linear_model1.chain(), self.linear_model2.chain()
             if ops.chain_small_ok(xf, c1 + c2) and c1[-1][0].shape[0] == self.embedding_layer.weight.shape[1]:
                 # inference on a small batch (config 3, B = 200): both MLPs and the time embedding in ONE launch
                 idx = idx.to(device=x.device, dtype=torch.int64).contiguous()

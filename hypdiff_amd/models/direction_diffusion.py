@@ -119,7 +119,7 @@ class gcndec(nn.Module):
         h = hag.GCNConvGelu.apply(h, w1, self.conv1.bias, csr, True)
         for conv in (self.conv2, self.conv3, self.conv4):
             h = hag.GCNConvGelu.apply(h, conv.lin.weight, conv.bias, csr, True)
-        if hag.wants_grad(h, *self.parameters()):
+        if torch.is_grad_enabled() and hag.wants_grad(h, *self.parameters()):
             return hag.linear_stack(h, [self.fc1, self.fc2, self.fc3], (hag.GELU, hag.GELU, hag.LIN))
         return ops.linear_chain(h, [(self.fc1.weight, self.fc1.bias, 1), (self.fc2.weight, self.fc2.bias, 1),
                                     (self.fc3.weight, self.fc3.bias, 0)])
@@ -165,7 +165,7 @@ class mlp(nn.Module):
                  (self.fc3.weight, self.fc3.bias, 1), (self.fc4.weight, self.fc4.bias, 1),
                  (self.fc5.weight, self.fc5.bias, 0)]
         fmt = ops.GEMM_MODE if ops.GEMM_MODE in ops.ROW_PACK_MAX_DIM else None
-        if fmt and d + 1 <= ops.ROW_PACK_MAX_DIM[fmt] and n > 0 and not hag.wants_grad(*self.parameters()):
+        if fmt and d + 1 <= ops.ROW_PACK_MAX_DIM[fmt] and n > 0 and not hag.chain_wants_grad(chain):
             # inference: the concat goes straight into the limb image of the first GEMM's operand
             img = ops.limb_empty(n, d + 1, x.device, fmt, zero_amax=False)
             if fmt == "f16x2":
@@ -186,7 +186,7 @@ class mlp(nn.Module):
         chain = [(self.fc1.weight, self.fc1.bias, 1), (self.fc2.weight, self.fc2.bias, 1),
                  (self.fc3.weight, self.fc3.bias, 1), (self.fc4.weight, self.fc4.bias, 1),
                  (self.fc5.weight, self.fc5.bias, 0)]
-        if hag.wants_grad(*self.parameters()):
+        if hag.chain_wants_grad(chain):
             # training (diff.py:113-118): forward and backward on HIP kernels, autograd only links them
             return hag.linear_stack(h, [self.fc1, self.fc2, self.fc3, self.fc4, self.fc5],
                                     (hag.GELU, hag.GELU, hag.GELU, hag.GELU, hag.LIN))
