@@ -5,12 +5,12 @@ set -e
 cd $GRAFT_REPO_ROOT
 bash tools/parity_margin.sh
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout -k 10 400 python3 bench.py > gpurun_out/r03_bench_v7.json 2> gpurun_out/r03_bench_v7.err
-timeout -k 10 400 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r03_bench_v7_driver_flags.json 2>> gpurun_out/r03_bench_v7.err
+timeout -k 10 400 python3 bench.py > gpurun_out/r03_bench_v8.json 2> gpurun_out/r03_bench_v8.err
+timeout -k 10 400 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r03_bench_v8_driver_flags.json 2>> gpurun_out/r03_bench_v8.err
 python3 -c "
 import json
-for f in ('gpurun_out/r03_bench_v7.json','gpurun_out/r03_bench_v7_driver_flags.json'):
+for f in ('gpurun_out/r03_bench_v8.json','gpurun_out/r03_bench_v8_driver_flags.json'):
     j=json.load(open(f)); print(j['ms_per_step'], j['value'], j['roofline']['frac'], j['roofline']['achieved'], j['one_stream']['ms_per_step'], j['train']['ms_per_step'], j['sharded']['ms_per_step'], j['cpu_baseline']['value'])"
-bash tools/prof_bench.sh r03f > gpurun_out/r03f_prof_summary.txt 2>&1; head -12 gpurun_out/r03f_prof_summary.txt | cut -c1-130
-bash tools/pmc_bench.sh r03f_bench; python3 -c "
-import json; j=json.load(open('gpurun_out/r03f_bench_hbm_traffic.json')); [print(k[:50], v) for k,v in j['kernels'].items() if 'chain' in k or 'gemm' in k]"
+bash tools/prof_bench.sh r03g > gpurun_out/r03g_prof_summary.txt 2>&1; head -12 gpurun_out/r03g_prof_summary.txt | cut -c1-130
+bash tools/pmc_bench.sh r03g_bench; python3 -c "
+import json; j=json.load(open('gpurun_out/r03g_bench_hbm_traffic.json')); [print(k[:50], v) for k,v in j['kernels'].items() if 'chain' in k or 'gemm' in k]"
