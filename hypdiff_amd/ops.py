@@ -214,6 +214,8 @@ def _pad_k(t, k_pad):
     """zero-pad the last dim of a 2-D tensor to k_pad columns (16-byte rows for the GEMM)"""
     if t.shape[1] == k_pad and t.is_contiguous() and t.data_ptr() % 16 == 0:
         return t
+    if t.shape[1] < k_pad:
+        return torch.nn.functional.pad(t, (0, k_pad - t.shape[1]))      # one launch (zeros + slice assignment were two)
     out = torch.zeros(t.shape[0], k_pad, dtype=t.dtype, device=t.device)
     out[:, : t.shape[1]] = t
     return out
